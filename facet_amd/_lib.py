@@ -1,0 +1,282 @@
+"""ctypes binding of libfacet_engine.so (C ABI: include/facet_engine.h).
+
+The product path has no CPU fallback: if the shared library or a gfx950 device is missing every
+entry point raises EngineError. Only plain pointers and sizes cross the boundary; numpy is used as
+the host buffer container.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfacet_engine.so")
+
+FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_SAMP, FE_MODEL_U2NETP, FE_MODEL_AESTHETIC = range(5)
+FE_MODEL_SCRFD, FE_MODEL_ARCFACE = 5, 6
+ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+_i64p = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); every symbol declared in include/facet_engine.h is listed here and
+# tests/test_abi.py checks the two stay in sync.
+SIGNATURES = {
+    "fe_create": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "fe_destroy": (None, [C.c_void_p]),
+    "fe_last_error": (C.c_char_p, [C.c_void_p]),
+    "fe_version": (C.c_char_p, []),
+    "fe_sync": (C.c_int, [C.c_void_p]),
+    "fe_set_microbatch": (C.c_int, [C.c_void_p, C.c_int]),
+    "fe_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "fe_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fe_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "fe_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "fe_timer_start": (C.c_int, [C.c_void_p]),
+    "fe_timer_stop": (C.c_int, [C.c_void_p, _f32p]),
+    "fe_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "fe_profile_count": (C.c_int, [C.c_void_p]),
+    "fe_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), _f32p]),
+    "fe_flops_reset": (C.c_int, [C.c_void_p]),
+    "fe_flops_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "fe_weights_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "fe_weights_set": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, _f32p, _i64p, C.c_int]),
+    "fe_weights_commit": (C.c_int, [C.c_void_p, C.c_int]),
+    "fe_model_unload": (C.c_int, [C.c_void_p, C.c_int]),
+    "fe_model_loaded": (C.c_int, [C.c_void_p, C.c_int]),
+    "fe_op_conv2d": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int,
+                               C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
+    "fe_op_maxpool2d": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, _f32p]),
+    "fe_op_bilinear": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
+    "fe_op_adaptive_avgpool": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         _f32p]),
+    "fe_op_layernorm": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_float, _f32p]),
+    "fe_topiq_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
+    "fe_topiq_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
+}
+
+
+def load_library():
+    """dlopen the in-tree engine; raises EngineError (never falls back) when it is missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise EngineError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise EngineError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+class Engine:
+    """One engine context = one GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device=0, arena_bytes=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.fe_create(int(device), int(arena_bytes), C.byref(h))
+        if rc != 0:
+            raise EngineError("fe_create failed: " + (self.lib.fe_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise EngineError((self.lib.fe_last_error(self.h) or b"?").decode())
+
+    # -- misc -------------------------------------------------------------------------------
+    def sync(self):
+        self._ck(self.lib.fe_sync(self.h))
+
+    def set_microbatch(self, n):
+        self._ck(self.lib.fe_set_microbatch(self.h, int(n)))
+
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._ck(self.lib.fe_dev_alloc(self.h, int(nbytes), C.byref(p)))
+        return p
+
+    def dev_free(self, p):
+        self._ck(self.lib.fe_dev_free(self.h, p))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._ck(self.lib.fe_memcpy_h2d(self.h, dptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        self._ck(self.lib.fe_memcpy_d2h(self.h, arr.ctypes.data_as(C.c_void_p), dptr, arr.nbytes))
+
+    def timer_start(self):
+        self._ck(self.lib.fe_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._ck(self.lib.fe_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self._ck(self.lib.fe_profile_enable(self.h, 1 if on else 0))
+
+    def profile_records(self):
+        out = []
+        n = self.lib.fe_profile_count(self.h)
+        buf = C.create_string_buffer(160)
+        for i in range(n):
+            fl, by, ms = C.c_double(), C.c_double(), C.c_float()
+            self._ck(self.lib.fe_profile_get(self.h, i, buf, 160, C.byref(fl), C.byref(by), C.byref(ms)))
+            out.append({"name": buf.value.decode(), "flops": fl.value, "bytes": by.value, "ms": ms.value})
+        return out
+
+    def flops_reset(self):
+        self._ck(self.lib.fe_flops_reset(self.h))
+
+    def flops(self):
+        v = C.c_double()
+        self._ck(self.lib.fe_flops_get(self.h, C.byref(v)))
+        return v.value
+
+    # -- weights ----------------------------------------------------------------------------
+    def load_weights(self, model, state_dict):
+        """state_dict: name -> array-like (numpy or torch CPU tensor), PyTorch checkpoint layout."""
+        self._ck(self.lib.fe_weights_begin(self.h, model))
+        for name, t in state_dict.items():
+            a = t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+            if a.dtype.kind not in "fiu" or a.ndim > 6:
+                continue
+            a, ap = _f32(a)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            self._ck(self.lib.fe_weights_set(self.h, model, name.encode(), ap, shape, a.ndim))
+        self._ck(self.lib.fe_weights_commit(self.h, model))
+
+    def unload(self, model):
+        self._ck(self.lib.fe_model_unload(self.h, model))
+
+    def loaded(self, model):
+        return bool(self.lib.fe_model_loaded(self.h, model))
+
+    # -- ops --------------------------------------------------------------------------------
+    def conv2d(self, x, w, scale=None, shift=None, res=None, res_after_act=False, stride=1, pad=0, dil=1, act=None):
+        x, xp = _f32(x)
+        w, wp = _f32(w)
+        n, c, h, ww = x.shape
+        cout, cin, kh, kw = w.shape
+        assert cin == c
+        ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        wo = (ww + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        y = np.empty((n, cout, ho, wo), np.float32)
+        sp = hp = rp = None
+        if scale is not None:
+            scale, sp = _f32(scale)
+        if shift is not None:
+            shift, hp = _f32(shift)
+        if res is not None:
+            res, rp = _f32(res)
+        self._ck(self.lib.fe_op_conv2d(self.h, xp, n, c, h, ww, wp, cout, kh, kw, sp, hp, rp, int(res_after_act),
+                                       stride, pad, dil, ACT[act], y.ctypes.data_as(_f32p)))
+        return y
+
+    def maxpool2d(self, x, k, stride, pad=0, ceil_mode=False):
+        x, xp = _f32(x)
+        n, c, h, w = x.shape
+
+        def od(i):
+            if ceil_mode:
+                o = -(-(i + 2 * pad - k) // stride) + 1
+                if (o - 1) * stride >= i + pad:
+                    o -= 1
+                return o
+            return (i + 2 * pad - k) // stride + 1
+        y = np.empty((n, c, od(h), od(w)), np.float32)
+        self._ck(self.lib.fe_op_maxpool2d(self.h, xp, n, c, h, w, k, stride, pad, int(ceil_mode),
+                                          y.ctypes.data_as(_f32p)))
+        return y
+
+    def bilinear(self, x, ho, wo):
+        x, xp = _f32(x)
+        n, c, h, w = x.shape
+        y = np.empty((n, c, ho, wo), np.float32)
+        self._ck(self.lib.fe_op_bilinear(self.h, xp, n, c, h, w, ho, wo, y.ctypes.data_as(_f32p)))
+        return y
+
+    def adaptive_avgpool(self, x, ho, wo):
+        x, xp = _f32(x)
+        n, c, h, w = x.shape
+        y = np.empty((n, c, ho, wo), np.float32)
+        self._ck(self.lib.fe_op_adaptive_avgpool(self.h, xp, n, c, h, w, ho, wo, y.ctypes.data_as(_f32p)))
+        return y
+
+    def layernorm(self, x, g, b, eps=1e-5):
+        x, xp = _f32(x)
+        g, gp = _f32(g)
+        b, bp = _f32(b)
+        rows, d = x.shape
+        y = np.empty_like(x)
+        self._ck(self.lib.fe_op_layernorm(self.h, xp, rows, d, gp, bp, eps, y.ctypes.data_as(_f32p)))
+        return y
+
+    # -- TOPIQ ------------------------------------------------------------------------------
+    @staticmethod
+    def _img_ptr(images):
+        """images: numpy uint8 [n,h,w,3] (host) or (device_ptr, n, h, w) tuple."""
+        if isinstance(images, tuple):
+            p, n, h, w = images
+            return p, n, h, w, 1, None
+        a = np.ascontiguousarray(images, dtype=np.uint8)
+        assert a.ndim == 4 and a.shape[3] == 3
+        return a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], a.shape[2], 0, a
+
+    def topiq_features(self, images, level):
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        div = [2, 4, 8, 16, 32][level]
+        ch = [64, 256, 512, 1024, 2048][level]
+        y = np.empty((n, ch, h // div, w // div), np.float32)
+        self._ck(self.lib.fe_topiq_features(self.h, p, n, h, w, dev, level, y.ctypes.data_as(_f32p)))
+        return y
+
+    def topiq_score(self, images):
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        y = np.empty((n,), np.float32)
+        self._ck(self.lib.fe_topiq_score(self.h, p, n, h, w, dev, y.ctypes.data_as(_f32p)))
+        return y

@@ -1,0 +1,338 @@
+// C ABI of libfacet_engine.so (declared in include/facet_engine.h).
+#include "../../include/facet_engine.h"
+#include "engine.h"
+
+using namespace fe;
+
+struct fe_ctx {
+  Ctx c;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  int microbatch = 8;
+};
+
+static std::string g_create_err;
+
+#define FE_API_BEGIN(ctx)                         \
+  if (!(ctx)) return FE_ERR_INVALID;              \
+  try {
+#define FE_API_END(ctx)                           \
+  }                                               \
+  catch (const std::exception& e) {               \
+    (ctx)->c.err = e.what();                      \
+    return FE_ERR_RUNTIME;                        \
+  }                                               \
+  return FE_OK;
+
+extern "C" {
+
+const char* fe_version(void) { return "facet_amd 0.1 (gfx950)"; }
+
+int fe_create(int device, size_t arena_bytes, fe_ctx** out) {
+  if (!out) return FE_ERR_INVALID;
+  *out = nullptr;
+  try {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) throw Error(std::string("no HIP device available: ") + hipGetErrorString(e));
+    FE_CHECK(device >= 0 && device < ndev, "device %d out of range (%d devices)", device, ndev);
+    FE_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FE_HIP(hipGetDeviceProperties(&prop, device));
+    FE_CHECK(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, "device %d is %s; this engine is built for gfx950 only",
+             device, prop.gcnArchName);
+    auto* x = new fe_ctx();
+    x->c.device = device;
+    FE_HIP(hipStreamCreateWithFlags(&x->c.stream, hipStreamNonBlocking));
+    x->c.arena.init(arena_bytes ? arena_bytes : ((size_t)8 << 30));
+    FE_HIP(hipEventCreate(&x->t0));
+    FE_HIP(hipEventCreate(&x->t1));
+    *out = x;
+  } catch (const std::exception& e) {
+    g_create_err = e.what();
+    return FE_ERR_RUNTIME;
+  }
+  return FE_OK;
+}
+
+void fe_destroy(fe_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->c.device);
+  (void)hipStreamSynchronize(ctx->c.stream);
+  if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+  if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  delete ctx;
+}
+
+const char* fe_last_error(fe_ctx* ctx) { return ctx ? ctx->c.err.c_str() : g_create_err.c_str(); }
+
+int fe_sync(fe_ctx* ctx) {
+  FE_API_BEGIN(ctx)
+  FE_HIP(hipStreamSynchronize(ctx->c.stream));
+  FE_API_END(ctx)
+}
+
+int fe_set_microbatch(fe_ctx* ctx, int n) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(n >= 1 && n <= 256, "microbatch %d out of range", n);
+  ctx->microbatch = n;
+  FE_API_END(ctx)
+}
+
+int fe_dev_alloc(fe_ctx* ctx, size_t bytes, void** d_out) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(d_out != nullptr, "null out");
+  FE_HIP(hipSetDevice(ctx->c.device));
+  FE_HIP(hipMalloc(d_out, bytes ? bytes : 16));
+  FE_API_END(ctx)
+}
+int fe_dev_free(fe_ctx* ctx, void* d_ptr) {
+  FE_API_BEGIN(ctx)
+  FE_HIP(hipFree(d_ptr));
+  FE_API_END(ctx)
+}
+int fe_memcpy_h2d(fe_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+  FE_API_BEGIN(ctx)
+  FE_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->c.stream));
+  FE_HIP(hipStreamSynchronize(ctx->c.stream));
+  FE_API_END(ctx)
+}
+int fe_memcpy_d2h(fe_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+  FE_API_BEGIN(ctx)
+  FE_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
+  FE_HIP(hipStreamSynchronize(ctx->c.stream));
+  FE_API_END(ctx)
+}
+
+int fe_timer_start(fe_ctx* ctx) {
+  FE_API_BEGIN(ctx)
+  FE_HIP(hipEventRecord(ctx->t0, ctx->c.stream));
+  FE_API_END(ctx)
+}
+int fe_timer_stop(fe_ctx* ctx, float* ms_out) {
+  FE_API_BEGIN(ctx)
+  FE_HIP(hipEventRecord(ctx->t1, ctx->c.stream));
+  FE_HIP(hipEventSynchronize(ctx->t1));
+  FE_HIP(hipEventElapsedTime(ms_out, ctx->t0, ctx->t1));
+  FE_API_END(ctx)
+}
+int fe_profile_enable(fe_ctx* ctx, int on) {
+  FE_API_BEGIN(ctx)
+  ctx->c.profile = on != 0;
+  ctx->c.timings.clear();
+  FE_API_END(ctx)
+}
+int fe_profile_count(fe_ctx* ctx) { return ctx ? (int)ctx->c.timings.size() : 0; }
+int fe_profile_get(fe_ctx* ctx, int i, char* name, int name_cap, double* flops, double* bytes, float* ms) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(i >= 0 && i < (int)ctx->c.timings.size(), "profile index %d", i);
+  const OpTiming& t = ctx->c.timings[i];
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s", t.name.c_str());
+  if (flops) *flops = t.flops;
+  if (bytes) *bytes = t.bytes;
+  if (ms) *ms = t.ms;
+  FE_API_END(ctx)
+}
+int fe_flops_reset(fe_ctx* ctx) {
+  FE_API_BEGIN(ctx)
+  ctx->c.flops_accum = 0.0;
+  FE_API_END(ctx)
+}
+int fe_flops_get(fe_ctx* ctx, double* flops) {
+  FE_API_BEGIN(ctx)
+  *flops = ctx->c.flops_accum;
+  FE_API_END(ctx)
+}
+
+// ---- weights ------------------------------------------------------------------------------------
+int fe_weights_begin(fe_ctx* ctx, int model) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(model >= 0 && model < 8, "model id %d", model);
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  ctx->c.staging[model].clear();
+  FE_API_END(ctx)
+}
+int fe_weights_set(fe_ctx* ctx, int model, const char* name, const float* data, const int64_t* shape, int ndim) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(model >= 0 && model < 8 && name && data && shape && ndim >= 0 && ndim <= 6, "bad arguments");
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  ctx->c.staging[model].set(name, data, shape, ndim);
+  FE_API_END(ctx)
+}
+int fe_weights_commit(fe_ctx* ctx, int model) {
+  FE_API_BEGIN(ctx)
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  FE_HIP(hipSetDevice(ctx->c.device));
+  WeightStore& ws = ctx->c.staging[model];
+  if (model == FE_MODEL_TOPIQ) {
+    auto m = std::make_unique<TopiqModel>();
+    const int blocks[4] = {3, 4, 6, 3};
+    build_resnet(m->backbone, m->dw, ws, "semantic_model.", true, blocks, false);
+    ctx->c.topiq = std::move(m);
+  } else {
+    throw Error("fe_weights_commit: model " + std::to_string(model) + " not implemented");
+  }
+  ws.clear();
+  FE_API_END(ctx)
+}
+int fe_model_unload(fe_ctx* ctx, int model) {
+  FE_API_BEGIN(ctx)
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  FE_HIP(hipStreamSynchronize(ctx->c.stream));
+  if (model == FE_MODEL_TOPIQ) ctx->c.topiq.reset();
+  FE_API_END(ctx)
+}
+int fe_model_loaded(fe_ctx* ctx, int model) {
+  if (!ctx) return 0;
+  if (model == FE_MODEL_TOPIQ) return ctx->c.topiq != nullptr;
+  return 0;
+}
+
+// ---- single ops -----------------------------------------------------------------------------------
+static Tensor upload_nchw(Ctx& c, const float* x, int n, int ch, int h, int w, int cpad) {
+  const size_t elems = (size_t)n * ch * h * w;
+  float* tmp = (float*)c.arena.alloc(elems * sizeof(float));
+  FE_HIP(hipMemcpyAsync(tmp, x, elems * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  Tensor t = c.arena.tensor(n, h, w, cpad);
+  launch_nchw_to_nhwc(tmp, t.p, n, ch, h, w, cpad, c.stream);
+  return t;
+}
+static void download_nchw(Ctx& c, const Tensor& t, int ch, float* y) {
+  const size_t elems = (size_t)t.n * ch * t.h * t.w;
+  float* tmp = (float*)c.arena.alloc(elems * sizeof(float));
+  launch_nhwc_to_nchw(t.p, t.ld, tmp, t.n, ch, t.h, t.w, c.stream);
+  FE_HIP(hipMemcpyAsync(y, tmp, elems * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+  FE_HIP(hipStreamSynchronize(c.stream));
+}
+
+int fe_op_conv2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, const float* weight, int cout, int kh, int kw,
+                 const float* scale, const float* shift, const float* res, int res_after_act, int stride, int pad,
+                 int dil, int act, float* y) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(x && weight && y && n > 0 && c > 0 && h > 0 && w > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0,
+           "bad conv arguments");
+  C.arena.reset();
+  DeviceWeights dw;
+  WeightStore ws;
+  const int64_t wshape[4] = {cout, c, kh, kw};
+  ws.set("w.weight", weight, wshape, 4);
+  ConvW cw = build_conv(dw, ws, "w", "", false);
+  std::vector<float> v;
+  if (scale) { v.assign(scale, scale + cout); cw.scale = dw.upload(v); }
+  if (shift) { v.assign(shift, shift + cout); cw.shift = dw.upload(v); }
+  Tensor xt = upload_nchw(C, x, n, c, h, w, cw.CinPad);
+  ConvOpts o;
+  o.sh = o.sw = stride; o.ph = o.pw = pad; o.dh = o.dw = dil; o.act = act; o.res_after_act = res_after_act;
+  const int ho = conv_out_dim(h, kh, stride, pad, dil), wo = conv_out_dim(w, kw, stride, pad, dil);
+  FE_CHECK(ho > 0 && wo > 0, "conv output is empty");
+  Tensor rt;
+  if (res) { rt = upload_nchw(C, res, n, cout, ho, wo, cout); o.res = &rt; }
+  Tensor yt = conv_new(C, cw, xt, o);
+  download_nchw(C, yt, cout, y);
+  FE_API_END(ctx)
+}
+
+int fe_op_maxpool2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int k, int stride, int pad, int ceil_mode,
+                    float* y) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  C.arena.reset();
+  Tensor xt = upload_nchw(C, x, n, c, h, w, c);
+  auto od = [&](int in) {
+    int o = ceil_mode ? (in + 2 * pad - k + stride - 1) / stride + 1 : (in + 2 * pad - k) / stride + 1;
+    if (ceil_mode && (o - 1) * stride >= in + pad) --o;
+    return o;
+  };
+  Tensor yt = C.arena.tensor(n, od(h), od(w), c);
+  launch_maxpool(xt, yt, k, stride, pad, C.stream);
+  download_nchw(C, yt, c, y);
+  FE_API_END(ctx)
+}
+
+int fe_op_bilinear(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int ho, int wo, float* y) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  C.arena.reset();
+  Tensor xt = upload_nchw(C, x, n, c, h, w, c);
+  Tensor yt = C.arena.tensor(n, ho, wo, c);
+  launch_bilinear(xt, yt, C.stream);
+  download_nchw(C, yt, c, y);
+  FE_API_END(ctx)
+}
+
+int fe_op_adaptive_avgpool(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int ho, int wo, float* y) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  C.arena.reset();
+  Tensor xt = upload_nchw(C, x, n, c, h, w, c);
+  Tensor yt = C.arena.tensor(n, ho, wo, c);
+  launch_adaptive_avgpool(xt, yt, C.stream);
+  download_nchw(C, yt, c, y);
+  FE_API_END(ctx)
+}
+
+int fe_op_layernorm(fe_ctx* ctx, const float* x, int rows, int d, const float* g, const float* b, float eps, float* y) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  C.arena.reset();
+  const size_t bytes = (size_t)rows * d * sizeof(float);
+  float* dx = (float*)C.arena.alloc(bytes);
+  float* dy = (float*)C.arena.alloc(bytes);
+  float* dg = (float*)C.arena.alloc(d * sizeof(float));
+  float* db = (float*)C.arena.alloc(d * sizeof(float));
+  FE_HIP(hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, C.stream));
+  FE_HIP(hipMemcpyAsync(dg, g, d * sizeof(float), hipMemcpyHostToDevice, C.stream));
+  FE_HIP(hipMemcpyAsync(db, b, d * sizeof(float), hipMemcpyHostToDevice, C.stream));
+  launch_layernorm(dx, d, dy, d, dg, db, rows, d, eps, C.stream);
+  FE_HIP(hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+// ---- TOPIQ ------------------------------------------------------------------------------------------
+static const float kImagenetMean[3] = {0.485f, 0.456f, 0.406f};
+static const float kImagenetStd[3] = {0.229f, 0.224f, 0.225f};
+
+// Runs the backbone on images [i0, i0+nb) of a device-resident u8 batch.
+static void topiq_backbone_chunk(fe_ctx* ctx, const uint8_t* d_rgb, int nb, int h, int w, std::vector<Tensor>& feats) {
+  Ctx& C = ctx->c;
+  Tensor x = C.arena.tensor(nb, h, w, 4);
+  launch_u8_to_nhwc4_norm(d_rgb, x.p, (size_t)nb * h * w, kImagenetMean, kImagenetStd, 0, C.stream);
+  resnet_forward(C, ctx->c.topiq->backbone, x, &feats);
+}
+
+int fe_topiq_features(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, int level, float* out) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  if (!C.topiq) { C.err = "topiq weights not loaded"; return FE_ERR_NOT_LOADED; }
+  FE_CHECK(rgb && out && n > 0 && h >= 32 && w >= 32 && level >= 0 && level <= 4, "bad arguments");
+  const size_t img_bytes = (size_t)h * w * 3;
+  size_t out_per_img = 0;
+  for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
+    const int nb = std::min(ctx->microbatch, n - i0);
+    C.arena.reset();
+    const uint8_t* d_in;
+    if (on_device) {
+      d_in = rgb + (size_t)i0 * img_bytes;
+    } else {
+      uint8_t* d = (uint8_t*)C.arena.alloc(nb * img_bytes);
+      FE_HIP(hipMemcpyAsync(d, rgb + (size_t)i0 * img_bytes, nb * img_bytes, hipMemcpyHostToDevice, C.stream));
+      d_in = d;
+    }
+    std::vector<Tensor> feats;
+    topiq_backbone_chunk(ctx, d_in, nb, h, w, feats);
+    const Tensor& f = feats[level];
+    out_per_img = (size_t)f.c * f.h * f.w;
+    download_nchw(C, f, f.c, out + (size_t)i0 * out_per_img);
+  }
+  FE_API_END(ctx)
+}
+
+int fe_topiq_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* scores) {
+  FE_API_BEGIN(ctx)
+  (void)rgb; (void)n; (void)h; (void)w; (void)on_device; (void)scores;
+  throw Error("fe_topiq_score: head not implemented yet");
+  FE_API_END(ctx)
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Engine-side runtime: context, weight store, layer builders and the model graphs of the hot path.
+#pragma once
+#include "fe_common.h"
+#include <memory>
+
+namespace fe {
+
+// Host copy of one named checkpoint tensor (fp32, contiguous, PyTorch layout).
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+  size_t numel() const { size_t n = 1; for (auto d : shape) n *= (size_t)d; return n; }
+};
+
+class WeightStore {
+ public:
+  void clear() { t_.clear(); }
+  void set(const std::string& name, const float* data, const int64_t* shape, int ndim);
+  bool has(const std::string& name) const { return t_.count(name) != 0; }
+  const HostTensor& get(const std::string& name) const;
+  size_t size() const { return t_.size(); }
+ private:
+  std::map<std::string, HostTensor> t_;
+};
+
+// Owns device copies of packed weights for one model; freed together.
+class DeviceWeights {
+ public:
+  ~DeviceWeights() { release(); }
+  float* upload(const std::vector<float>& v);
+  void release();
+  size_t bytes() const { return bytes_; }
+ private:
+  std::vector<void*> ptrs_;
+  size_t bytes_ = 0;
+};
+
+struct Linear {  // y = x W^T + b, stored as a 1x1 ConvW
+  ConvW w;
+};
+
+struct LayerNormW {
+  float* g = nullptr; float* b = nullptr; int d = 0; float eps = 1e-5f;
+};
+
+// Build helpers ------------------------------------------------------------------------------------
+// conv (OIHW) with optional bias and optional eval-mode BatchNorm folded into per-channel scale/shift.
+ConvW build_conv(DeviceWeights& dw, const WeightStore& ws, const std::string& conv_prefix,
+                 const std::string& bn_prefix, bool conv_bias, float bn_eps = 1e-5f);
+// nn.Linear weight [out][in] (+bias) as a 1x1 conv
+ConvW build_linear(DeviceWeights& dw, const WeightStore& ws, const std::string& prefix, bool bias);
+// same from explicit tensor names / row ranges (for fused in_proj splits)
+ConvW build_linear_rows(DeviceWeights& dw, const HostTensor& w, const HostTensor* b, int row0, int rows);
+LayerNormW build_ln(DeviceWeights& dw, const WeightStore& ws, const std::string& prefix, float eps = 1e-5f);
+
+struct Ctx;
+
+// Runs conv on views; allocates nothing. Output spatial dims must already be set on y.
+void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, const ConvOpts& o);
+// Allocates the output from the arena with the standard conv output size.
+Tensor conv_new(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o);
+inline int conv_out_dim(int in, int k, int s, int p, int d) { return (in + 2 * p - d * (k - 1) - 1) / s + 1; }
+
+// ---- ResNet (timm resnet50 features_only / torchvision resnet18 children[:-2]) -------------------
+struct ResBlock {
+  ConvW c1, c2, c3, down;
+  bool has_down = false, bottleneck = true;
+  int stride = 1;
+};
+struct ResNet {
+  ConvW stem;
+  std::vector<std::vector<ResBlock>> layers;
+  bool bottleneck = true;
+};
+// keys: prefix + {conv1,bn1,layer1.0.conv1,...} (timm/torchvision naming) or the Sequential numbering
+// of reference models/samp_net.py:652-662 when `seq_names` is true (0=conv1,1=bn1,4..7=layer1..4).
+void build_resnet(ResNet& r, DeviceWeights& dw, const WeightStore& ws, const std::string& prefix,
+                  bool bottleneck, const int blocks[4], bool seq_names);
+// feats (optional) receives [stem-relu, layer1..layer4]; returns layer4 output.
+Tensor resnet_forward(Ctx& c, const ResNet& r, const Tensor& x_nhwc4, std::vector<Tensor>* feats);
+
+struct OpTiming { std::string name; double flops; double bytes; float ms; };
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Arena arena;
+  std::string err;
+  std::mutex mu;
+  // per-op profiling (off by default): records events around each conv launch
+  bool profile = false;
+  std::vector<OpTiming> timings;
+  double flops_accum = 0.0;
+
+  WeightStore staging[8];
+  std::unique_ptr<struct TopiqModel> topiq;
+  ~Ctx();
+};
+
+struct TopiqModel {
+  DeviceWeights dw;
+  ResNet backbone;
+  bool has_head = false;
+};
+
+}  // namespace fe

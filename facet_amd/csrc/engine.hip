@@ -1,0 +1,236 @@
+// Engine runtime: weight packing, conv/linear wrappers and the ResNet graphs.
+#include "engine.h"
+#include <cmath>
+
+namespace fe {
+
+void WeightStore::set(const std::string& name, const float* data, const int64_t* shape, int ndim) {
+  HostTensor h;
+  h.shape.assign(shape, shape + ndim);
+  h.data.assign(data, data + h.numel());
+  t_[name] = std::move(h);
+}
+const HostTensor& WeightStore::get(const std::string& name) const {
+  auto it = t_.find(name);
+  if (it == t_.end()) throw Error("missing weight tensor '" + name + "'");
+  return it->second;
+}
+
+float* DeviceWeights::upload(const std::vector<float>& v) {
+  void* p = nullptr;
+  const size_t b = v.size() * sizeof(float);
+  FE_HIP(hipMalloc(&p, b ? b : 16));
+  if (b) FE_HIP(hipMemcpy(p, v.data(), b, hipMemcpyHostToDevice));
+  ptrs_.push_back(p);
+  bytes_ += b;
+  return (float*)p;
+}
+void DeviceWeights::release() {
+  for (void* p : ptrs_) (void)hipFree(p);
+  ptrs_.clear();
+  bytes_ = 0;
+}
+
+Ctx::~Ctx() {
+  topiq.reset();
+  arena.release();
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+static ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>* scale,
+                       const std::vector<float>* shift) {
+  FE_CHECK(w.shape.size() == 4 || w.shape.size() == 2, "conv weight rank %zu", w.shape.size());
+  ConvW c;
+  c.Cout = (int)w.shape[0];
+  c.Cin = (int)w.shape[1];
+  c.KH = w.shape.size() == 4 ? (int)w.shape[2] : 1;
+  c.KW = w.shape.size() == 4 ? (int)w.shape[3] : 1;
+  c.CinPad = (c.Cin + 3) & ~3;
+  c.K = c.KH * c.KW * c.CinPad;
+  c.Kp = (c.K + CONV_KALIGN - 1) / CONV_KALIGN * CONV_KALIGN;
+  std::vector<float> packed((size_t)c.Cout * c.Kp, 0.f);
+  for (int co = 0; co < c.Cout; ++co)
+    for (int ci = 0; ci < c.Cin; ++ci)
+      for (int kh = 0; kh < c.KH; ++kh)
+        for (int kw = 0; kw < c.KW; ++kw)
+          packed[(size_t)co * c.Kp + (size_t)(kh * c.KW + kw) * c.CinPad + ci] =
+              w.data[(((size_t)co * c.Cin + ci) * c.KH + kh) * c.KW + kw];
+  c.w = dw.upload(packed);
+  if (scale) c.scale = dw.upload(*scale);
+  if (shift) c.shift = dw.upload(*shift);
+  return c;
+}
+
+ConvW build_conv(DeviceWeights& dw, const WeightStore& ws, const std::string& conv_prefix,
+                 const std::string& bn_prefix, bool conv_bias, float bn_eps) {
+  const HostTensor& w = ws.get(conv_prefix + ".weight");
+  const int cout = (int)w.shape[0];
+  std::vector<float> scale, shift;
+  const bool bn = !bn_prefix.empty();
+  if (bn) {
+    const auto& g = ws.get(bn_prefix + ".weight").data;
+    const auto& b = ws.get(bn_prefix + ".bias").data;
+    const auto& mu = ws.get(bn_prefix + ".running_mean").data;
+    const auto& var = ws.get(bn_prefix + ".running_var").data;
+    FE_CHECK((int)g.size() == cout && (int)var.size() == cout, "bn %s size mismatch", bn_prefix.c_str());
+    scale.resize(cout); shift.resize(cout);
+    for (int i = 0; i < cout; ++i) {
+      const float inv = 1.0f / std::sqrt(var[i] + bn_eps);
+      scale[i] = g[i] * inv;
+      float sh = b[i] - mu[i] * scale[i];
+      if (conv_bias) sh += ws.get(conv_prefix + ".bias").data[i] * scale[i];
+      shift[i] = sh;
+    }
+  } else if (conv_bias) {
+    shift = ws.get(conv_prefix + ".bias").data;
+    FE_CHECK((int)shift.size() == cout, "bias %s size mismatch", conv_prefix.c_str());
+  }
+  return pack_conv(dw, w, scale.empty() ? nullptr : &scale, shift.empty() ? nullptr : &shift);
+}
+
+ConvW build_linear(DeviceWeights& dw, const WeightStore& ws, const std::string& prefix, bool bias) {
+  const HostTensor& w = ws.get(prefix + ".weight");
+  FE_CHECK(w.shape.size() == 2, "linear %s weight rank", prefix.c_str());
+  if (bias) {
+    const auto& b = ws.get(prefix + ".bias").data;
+    return pack_conv(dw, w, nullptr, &b);
+  }
+  return pack_conv(dw, w, nullptr, nullptr);
+}
+
+ConvW build_linear_rows(DeviceWeights& dw, const HostTensor& w, const HostTensor* b, int row0, int rows) {
+  FE_CHECK(w.shape.size() == 2 && row0 + rows <= w.shape[0], "linear_rows: bad range");
+  HostTensor sub;
+  const int in = (int)w.shape[1];
+  sub.shape = {rows, in};
+  sub.data.assign(w.data.begin() + (size_t)row0 * in, w.data.begin() + (size_t)(row0 + rows) * in);
+  if (b) {
+    std::vector<float> bb(b->data.begin() + row0, b->data.begin() + row0 + rows);
+    return pack_conv(dw, sub, nullptr, &bb);
+  }
+  return pack_conv(dw, sub, nullptr, nullptr);
+}
+
+LayerNormW build_ln(DeviceWeights& dw, const WeightStore& ws, const std::string& prefix, float eps) {
+  LayerNormW l;
+  const auto& g = ws.get(prefix + ".weight").data;
+  l.d = (int)g.size();
+  l.g = dw.upload(g);
+  l.b = dw.upload(ws.get(prefix + ".bias").data);
+  l.eps = eps;
+  return l;
+}
+
+void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, const ConvOpts& o) {
+  FE_CHECK(x.c == w.CinPad, "conv: input channels %d != packed Cin %d", x.c, w.CinPad);
+  FE_CHECK(y.c == w.Cout && y.n == x.n, "conv: output view mismatch (c=%d Cout=%d)", y.c, w.Cout);
+  ConvParams p{};
+  p.x = x.p; p.ldx = x.ld;
+  p.w = w.w; p.scale = w.scale; p.shift = w.shift;
+  if (o.res) {
+    FE_CHECK(o.res->c == y.c && o.res->pixels() == y.pixels(), "conv: residual shape mismatch");
+    p.res = o.res->p; p.ldr = o.res->ld;
+  }
+  if (o.gate) {
+    FE_CHECK(o.gate->pixels() == y.pixels() && (o.gate->c == 1 || o.gate->c == y.c), "conv: gate shape mismatch");
+    p.gate = o.gate->p; p.ldg = o.gate->ld; p.gate_c1 = o.gate->c == 1;
+  }
+  p.y = y.p; p.ldy = y.ld;
+  p.N = x.n; p.H = x.h; p.W = x.w; p.Cin = w.CinPad;
+  p.Ho = y.h; p.Wo = y.w; p.Cout = w.Cout;
+  p.KH = w.KH; p.KW = w.KW; p.sh = o.sh; p.sw = o.sw; p.ph = o.ph; p.pw = o.pw; p.dh = o.dh; p.dw = o.dw;
+  FE_CHECK(y.h == conv_out_dim(x.h, w.KH, o.sh, o.ph, o.dh) && y.w == conv_out_dim(x.w, w.KW, o.sw, o.pw, o.dw),
+           "conv: output dims %dx%d inconsistent with input %dx%d", y.h, y.w, x.h, x.w);
+  p.K = w.K; p.Kp = w.Kp;
+  p.M = (int)y.pixels();
+  FE_CHECK(y.pixels() < (1ull << 31), "conv: M too large");
+  p.act = o.act; p.res_after_act = o.res_after_act;
+  if (c.profile) {
+    hipEvent_t e0, e1;
+    FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
+    FE_HIP(hipEventRecord(e0, c.stream));
+    launch_conv(p, c.stream);
+    FE_HIP(hipEventRecord(e1, c.stream));
+    FE_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FE_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    char nm[128];
+    snprintf(nm, sizeof nm, "conv%dx%d s%d d%d M=%d K=%d N=%d", w.KH, w.KW, o.sh, o.dh, p.M, p.K, p.Cout);
+    double bytes = 4.0 * ((double)x.pixels() * x.c + (double)y.pixels() * y.c * (o.res ? 2 : 1) + (double)w.Cout * w.K);
+    c.timings.push_back({nm, 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * p.Cout, bytes, ms});
+  } else {
+    launch_conv(p, c.stream);
+  }
+  c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * p.Cout;
+}
+
+Tensor conv_new(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o) {
+  Tensor y = c.arena.tensor(x.n, conv_out_dim(x.h, w.KH, o.sh, o.ph, o.dh), conv_out_dim(x.w, w.KW, o.sw, o.pw, o.dw), w.Cout);
+  conv_forward(c, w, x, y, o);
+  return y;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ResNet
+// ---------------------------------------------------------------------------------------------------
+void build_resnet(ResNet& r, DeviceWeights& dw, const WeightStore& ws, const std::string& prefix,
+                  bool bottleneck, const int blocks[4], bool seq_names) {
+  r.bottleneck = bottleneck;
+  auto nm = [&](const char* plain, int seq) { return prefix + (seq_names ? std::to_string(seq) : std::string(plain)); };
+  r.stem = build_conv(dw, ws, nm("conv1", 0), nm("bn1", 1), false);
+  r.layers.clear();
+  for (int li = 0; li < 4; ++li) {
+    std::vector<ResBlock> L;
+    const std::string lp = seq_names ? prefix + std::to_string(4 + li) : prefix + "layer" + std::to_string(li + 1);
+    for (int bi = 0; bi < blocks[li]; ++bi) {
+      const std::string bp = lp + "." + std::to_string(bi);
+      ResBlock b;
+      b.bottleneck = bottleneck;
+      b.stride = (bi == 0 && li > 0) ? 2 : 1;
+      b.c1 = build_conv(dw, ws, bp + ".conv1", bp + ".bn1", false);
+      b.c2 = build_conv(dw, ws, bp + ".conv2", bp + ".bn2", false);
+      if (bottleneck) b.c3 = build_conv(dw, ws, bp + ".conv3", bp + ".bn3", false);
+      b.has_down = ws.has(bp + ".downsample.0.weight");
+      if (b.has_down) b.down = build_conv(dw, ws, bp + ".downsample.0", bp + ".downsample.1", false);
+      L.push_back(b);
+    }
+    r.layers.push_back(std::move(L));
+  }
+}
+
+Tensor resnet_forward(Ctx& c, const ResNet& r, const Tensor& x, std::vector<Tensor>* feats) {
+  ConvOpts so; so.sh = so.sw = 2; so.ph = so.pw = 3; so.act = ACT_RELU;
+  Tensor t = conv_new(c, r.stem, x, so);
+  if (feats) feats->push_back(t);
+  Tensor p = c.arena.tensor(t.n, conv_out_dim(t.h, 3, 2, 1, 1), conv_out_dim(t.w, 3, 2, 1, 1), t.c);
+  launch_maxpool(t, p, 3, 2, 1, c.stream);
+  t = p;
+  for (size_t li = 0; li < r.layers.size(); ++li) {
+    for (const ResBlock& b : r.layers[li]) {
+      Tensor idt = t;
+      if (b.has_down) {
+        ConvOpts d; d.sh = d.sw = b.stride;
+        idt = conv_new(c, b.down, t, d);
+      }
+      if (b.bottleneck) {
+        // torchvision v1.5 / timm: stride sits on the 3x3 (conv2)
+        ConvOpts o1; o1.act = ACT_RELU;
+        Tensor a = conv_new(c, b.c1, t, o1);
+        ConvOpts o2; o2.sh = o2.sw = b.stride; o2.ph = o2.pw = 1; o2.act = ACT_RELU;
+        Tensor bb = conv_new(c, b.c2, a, o2);
+        ConvOpts o3; o3.act = ACT_RELU; o3.res = &idt;
+        t = conv_new(c, b.c3, bb, o3);
+      } else {
+        ConvOpts o1; o1.sh = o1.sw = b.stride; o1.ph = o1.pw = 1; o1.act = ACT_RELU;
+        Tensor a = conv_new(c, b.c1, t, o1);
+        ConvOpts o2; o2.ph = o2.pw = 1; o2.act = ACT_RELU; o2.res = &idt;
+        t = conv_new(c, b.c2, a, o2);
+      }
+    }
+    if (feats) feats->push_back(t);
+  }
+  return t;
+}
+
+}  // namespace fe

@@ -1,0 +1,165 @@
+// facet_amd engine — shared declarations for the HIP kernels and the C-ABI layer.
+// gfx950 (MI355X) only. No torch types anywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace fe {
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define FE_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      char _b[512];                                                                       \
+      snprintf(_b, sizeof _b, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,               \
+               hipGetErrorString(_e));                                                    \
+      throw fe::Error(_b);                                                                \
+    }                                                                                     \
+  } while (0)
+
+#define FE_CHECK(cond, ...)                                                               \
+  do {                                                                                    \
+    if (!(cond)) {                                                                        \
+      char _b[512];                                                                       \
+      int _n = snprintf(_b, sizeof _b, "%s:%d: check failed (%s): ", __FILE__, __LINE__,  \
+                        #cond);                                                           \
+      snprintf(_b + _n, sizeof _b - _n, __VA_ARGS__);                                     \
+      throw fe::Error(_b);                                                                \
+    }                                                                                     \
+  } while (0)
+
+// Activation codes shared by the GEMM/conv epilogue.
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
+
+// A view of an NHWC fp32 activation in HBM. `ld` is the channel stride of one pixel
+// (>= c) so a view can be a channel slice of a wider (concat) buffer.
+struct Tensor {
+  float* p = nullptr;
+  int n = 0, h = 0, w = 0, c = 0;
+  int ld = 0;
+  size_t pixels() const { return (size_t)n * h * w; }
+  size_t numel() const { return pixels() * c; }
+  Tensor slice(int c0, int cn) const {
+    Tensor t = *this;
+    t.p = p + c0;
+    t.c = cn;
+    return t;
+  }
+};
+
+// Bump allocator over one hipMalloc'ed slab; reset per forward. 256-B aligned.
+class Arena {
+ public:
+  void init(size_t bytes) {
+    release();
+    FE_HIP(hipMalloc(&base_, bytes));
+    cap_ = bytes;
+    off_ = 0;
+  }
+  void release() {
+    if (base_) (void)hipFree(base_);
+    base_ = nullptr;
+    cap_ = off_ = 0;
+  }
+  ~Arena() { release(); }
+  void reset() { off_ = 0; }
+  size_t mark() const { return off_; }
+  void rewind(size_t m) { off_ = m; }
+  size_t capacity() const { return cap_; }
+  size_t high_water() const { return high_; }
+  void* alloc(size_t bytes) {
+    size_t a = (off_ + 255) & ~(size_t)255;
+    FE_CHECK(a + bytes <= cap_, "arena exhausted: need %zu at %zu of %zu", bytes, a, cap_);
+    off_ = a + bytes;
+    if (off_ > high_) high_ = off_;
+    return (char*)base_ + a;
+  }
+  Tensor tensor(int n, int h, int w, int c) {
+    Tensor t;
+    t.n = n; t.h = h; t.w = w; t.c = c; t.ld = c;
+    t.p = (float*)alloc(t.numel() * sizeof(float));
+    return t;
+  }
+ private:
+  void* base_ = nullptr;
+  size_t cap_ = 0, off_ = 0, high_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------
+// Implicit-GEMM convolution / GEMM (kernels_conv.hip)
+// ---------------------------------------------------------------------------------------
+struct ConvParams {
+  const float* x; int ldx;          // input NHWC view
+  const float* w;                   // packed [Cout][Kp], k = (kh, kw, ci) with ci fastest, zero padded to Kp
+  const float* scale;               // per-Cout multiply (nullable => 1)
+  const float* shift;               // per-Cout add (nullable => 0)
+  const float* res; int ldr;        // residual view, same N,Ho,Wo,Cout (nullable)
+  const float* gate; int ldg;       // multiplicative gate, ldg==... (nullable); gate_c1: single channel broadcast
+  float* y; int ldy;                // output NHWC view
+  int N, H, W, Cin, Ho, Wo, Cout;
+  int KH, KW, sh, sw, ph, pw, dh, dw;
+  int K, Kp, M;
+  int act;                          // Act
+  int res_after_act;                // 1: y = act(conv*scale+shift) + res ; 0: y = act(conv*scale+shift+res)
+  int gate_c1;                      // 1: gate has one channel (broadcast over Cout)
+};
+
+// Packed conv weight living in HBM.
+struct ConvW {
+  float* w = nullptr;      // [Cout][Kp]
+  float* scale = nullptr;  // [Cout] or null
+  float* shift = nullptr;  // [Cout] or null
+  int Cout = 0, Cin = 0, CinPad = 0, KH = 1, KW = 1, K = 0, Kp = 0;
+};
+
+struct ConvOpts {
+  int sh = 1, sw = 1, ph = 0, pw = 0, dh = 1, dw = 1;
+  int act = ACT_NONE;
+  const Tensor* res = nullptr;
+  int res_after_act = 0;
+  const Tensor* gate = nullptr;
+};
+
+constexpr int CONV_KALIGN = 32;  // Kp is a multiple of this (covers BK = 16 and 32)
+
+void launch_conv(const ConvParams& p, hipStream_t s);
+double conv_flops(const ConvParams& p);
+
+// ---------------------------------------------------------------------------------------
+// Misc kernels (kernels_misc.hip)
+// ---------------------------------------------------------------------------------------
+// u8 HWC RGB -> fp32 NHWC4 ((v/255 - mean)/std, 4th channel 0). bgr: input channel order is BGR.
+void launch_u8_to_nhwc4_norm(const uint8_t* src, float* dst, size_t pixels, const float mean[3],
+                             const float stdv[3], int bgr, hipStream_t s);
+// fp32 NCHW -> NHWC(c padded to cpad with zeros)
+void launch_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, int cpad,
+                         hipStream_t s);
+void launch_nhwc_to_nchw(const float* src, int lds_, float* dst, int n, int c, int h, int w,
+                         hipStream_t s);
+// max pool, NHWC; ceil_mode handled by caller through Ho/Wo; padding implicit -inf.
+void launch_maxpool(const Tensor& x, const Tensor& y, int k, int stride, int pad, hipStream_t s);
+// bilinear resize (align_corners=False), NHWC.
+void launch_bilinear(const Tensor& x, const Tensor& y, hipStream_t s);
+// adaptive average pool NHWC -> NHWC (torch semantics: start=floor(i*H/Ho), end=ceil((i+1)*H/Ho))
+void launch_adaptive_avgpool(const Tensor& x, const Tensor& y, hipStream_t s);
+// y = act(x) elementwise / y = x + r
+void launch_sigmoid(const Tensor& x, const Tensor& y, hipStream_t s);
+void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s);
+// LayerNorm over last dim of a [rows][d] matrix (eps inside sqrt, biased variance)
+void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,
+                      int rows, int d, float eps, hipStream_t s);
+// rows softmax in place for [rows][d]
+void launch_softmax_rows(float* x, int ld, int rows, int d, hipStream_t s);
+
+}  // namespace fe

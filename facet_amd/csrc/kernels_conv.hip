@@ -1,0 +1,240 @@
+// Implicit-GEMM convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+//   Y[m][co] = act( (sum_k A[m][k] * Wt[co][k]) * scale[co] + shift[co] (+ res[m][co]) )
+//   m = (n, oh, ow) output pixel,  k = (kh, kw, ci) with ci fastest (NHWC im2col, never materialised)
+//
+// One kernel covers every dense contraction of the hot path: ResNet-50 / ResNet-18 / U2-Net-P
+// convolutions, the ViT patch-embed + QKV/proj/MLP GEMMs (a GEMM is a 1x1 "conv" over an [M][K]
+// matrix) and the TOPIQ head. Replaces cuDNN/ATen conv2d + batch_norm + relu reached from
+// reference models/pyiqa_scorer.py:212 (pyiqa -> timm resnet50) and models/samp_net.py:49-54,772.
+//
+// Tiling: 256 threads = 4 waves (64 lanes). Wave tile = (TM*32) x (TN*32) built from 32x32x2 fp32
+// MFMAs; block tile BM x BN = (WGM*TM*32) x (WGN*TN*32); K staged through LDS in BK-wide slabs,
+// double buffered, register-prefetched (global->VGPR issued before the MFMA phase, VGPR->LDS after it).
+// LDS rows are k-contiguous with a +4 float pad so the ds_read_b128 fragment reads are conflict free
+// (row*(BK+4) mod 64 hits 16 distinct 16-B slots per 16-lane group).
+// The k order inside an 8-wide step is permuted (lane half h, element j <-> k = 8s + 4h + j) so each
+// lane fetches its four A (and B) operands of a step with ONE 16-byte LDS read.
+#include "fe_common.h"
+
+namespace fe {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  return v;
+}
+
+template <int WGM, int WGN, int TM, int TN, int BK, bool FAST>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, const int ntiles) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  constexpr int S = BK + 4;        // LDS row stride (floats)
+  constexpr int CH = BK / 4;       // 16-B chunks per row
+  constexpr int RPP = 256 / CH;    // rows covered per staging pass
+  constexpr int AP = (BM + RPP - 1) / RPP, BP = (BN + RPP - 1) / RPP;
+  static_assert(WGM * WGN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][BM][S]
+  float* Bs = smem + 2 * BM * S;    // [2][BN][S]
+
+  // XCD-aware bijective remap: blocks b and b+8 share an XCD (private L2); give each XCD a contiguous
+  // run of tiles so the N-tiles of one M-tile (same A panel) and neighbouring M-tiles (halo rows) hit L2.
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+  const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int mt = swz / ntiles, nt = swz - mt * ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- staging coordinates -----------------------------------------------------------
+  const int chunk = t % CH, srow = t / CH;
+  const int HoWo = p.Ho * p.Wo;
+  int ih0[AP], iw0[AP];
+  size_t abase[AP];
+  bool mval[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int row = srow + i * RPP;
+    const int m = m0 + row;
+    mval[i] = (row < BM) && (m < p.M);
+    const int mm = mval[i] ? m : 0;
+    const int nimg = mm / HoWo;
+    const int rem = mm - nimg * HoWo;
+    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+    ih0[i] = oh * p.sh - p.ph;
+    iw0[i] = ow * p.sw - p.pw;
+    abase[i] = (size_t)nimg * p.H * p.W;
+  }
+  // running (kh, kw, ci) of this thread's chunk (FAST: ci0 is block-uniform, chunk added at use)
+  int kh, kw, ci;
+  if (FAST) {
+    kh = 0; kw = 0; ci = 0;
+  } else {
+    const int kk = chunk * 4;
+    const int tap = kk / p.Cin;
+    ci = kk - tap * p.Cin;
+    kh = tap / p.KW;
+    kw = tap - kh * p.KW;
+  }
+  const float* wrow[BP];
+  bool nval[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int row = srow + i * RPP;
+    const int n = n0 + row;
+    nval[i] = (row < BN) && (n < p.Cout);
+    wrow[i] = p.w + (size_t)(nval[i] ? n : 0) * p.Kp + chunk * 4;
+  }
+
+  float4 ra[AP], rb[BP];
+  const int nk = p.Kp / BK;
+
+  auto load_tile = [&](int kt) {
+    const int cofs = FAST ? ci + chunk * 4 : ci;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int ih = ih0[i] + kh * p.dh, iw = iw0[i] + kw * p.dw;
+      const bool ok = mval[i] && (kh < p.KH) && ((unsigned)ih < (unsigned)p.H) &&
+                      ((unsigned)iw < (unsigned)p.W);
+      if (ok) {
+        const float* src = p.x + (abase[i] + (size_t)ih * p.W + iw) * p.ldx + cofs;
+        ra[i] = *reinterpret_cast<const float4*>(src);
+      } else {
+        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      if (nval[i]) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + (size_t)kt * BK);
+      else rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // advance k state to the next slab
+    ci += BK;
+    while (ci >= p.Cin) {
+      ci -= p.Cin;
+      if (++kw == p.KW) { kw = 0; ++kh; }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int row = srow + i * RPP;
+      if (row < BM) *reinterpret_cast<float4*>(&As[(buf * BM + row) * S + chunk * 4]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int row = srow + i * RPP;
+      if (row < BN) *reinterpret_cast<float4*>(&Bs[(buf * BN + row) * S + chunk * 4]) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int arow = wm * TM * 32 + r, brow = wn * TN * 32 + r;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const float* Ab = As + (buf * BM + arow) * S + h * 4;
+    const float* Bb = Bs + (buf * BN + brow) * S + h * 4;
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * S + s * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * S + s * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * TN * 32 + j * 32 + r;
+    const bool cok = col < p.Cout;
+    const float sc = (cok && p.scale) ? p.scale[col] : 1.f;
+    const float sf = (cok && p.shift) ? p.shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = m0 + row;
+        if (cok && m < p.M) {
+          float v = acc[i][j][e] * sc + sf;
+          if (p.res && !p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
+          v = apply_act(v, p.act);
+          if (p.res && p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
+          if (p.gate) v *= p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
+          p.y[(size_t)m * p.ldy + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int WGM, int WGN, int TM, int TN, int BK, bool FAST>
+static void launch_variant(const ConvParams& p, hipStream_t s) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
+  const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+  auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, BK, FAST>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, s, p, ntiles);
+  FE_HIP(hipGetLastError());
+}
+
+double conv_flops(const ConvParams& p) { return 2.0 * (double)p.M * p.K * p.Cout; }
+
+void launch_conv(const ConvParams& p, hipStream_t s) {
+  FE_CHECK(p.Cin % 4 == 0 && p.ldx % 4 == 0, "conv: Cin=%d ldx=%d must be multiples of 4", p.Cin, p.ldx);
+  FE_CHECK(((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.w & 15) == 0, "conv: x/w must be 16-B aligned");
+  FE_CHECK(p.Kp % CONV_KALIGN == 0 && p.Kp >= p.K, "conv: bad Kp=%d K=%d", p.Kp, p.K);
+  FE_CHECK(p.M > 0 && p.Cout > 0, "conv: empty problem");
+  FE_CHECK((long long)p.N * p.H * p.W < (1ll << 31), "conv: too many input pixels");
+  const bool fast = (p.Cin % 16 == 0);
+  // Tile choice: wide-N tiles for Cout >= 128, tall tiles for narrow outputs.
+  if (p.Cout > 64) {
+    if (fast) launch_variant<2, 2, 2, 2, 16, true>(p, s);
+    else launch_variant<2, 2, 2, 2, 16, false>(p, s);
+  } else if (p.Cout > 32) {
+    if (fast) launch_variant<4, 1, 2, 2, 16, true>(p, s);
+    else launch_variant<4, 1, 2, 2, 16, false>(p, s);
+  } else {
+    if (fast) launch_variant<4, 1, 2, 1, 16, true>(p, s);
+    else launch_variant<4, 1, 2, 1, 16, false>(p, s);
+  }
+}
+
+}  // namespace fe

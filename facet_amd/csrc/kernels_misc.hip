@@ -1,0 +1,262 @@
+// HBM-bound helper kernels of the scoring hot path: pixel preprocessing, pooling, resampling,
+// LayerNorm / softmax rows. All operate on NHWC fp32 views (see fe::Tensor) with 16-byte vector
+// accesses where the channel count allows; grid capped at 2048 blocks with grid-stride loops.
+#include "fe_common.h"
+
+namespace fe {
+
+static inline int grid_for(size_t work, int block = 256) {
+  size_t g = (work + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- u8 HWC (RGB or BGR) -> fp32 NHWC4, ((v/255) - mean)/std --------------------------------------
+// Mirrors reference models/pyiqa_scorer.py:155-158 (array/255, HWC->CHW) followed by the model's own
+// ImageNet normalisation; channel 3 is zero so the stem conv can use 16-B pixel loads.
+__global__ void u8_to_nhwc4_kernel(const uint8_t* __restrict__ src, float4* __restrict__ dst, size_t pixels,
+                                   float m0, float m1, float m2, float s0, float s1, float s2, int bgr) {
+  // 4 pixels (12 bytes = 3 dwords) per thread
+  const size_t groups = pixels / 4;
+  const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t a = s32[g * 3 + 0], b = s32[g * 3 + 1], c = s32[g * 3 + 2];
+    uint8_t px[12];
+    px[0] = a; px[1] = a >> 8; px[2] = a >> 16; px[3] = a >> 24;
+    px[4] = b; px[5] = b >> 8; px[6] = b >> 16; px[7] = b >> 24;
+    px[8] = c; px[9] = c >> 8; px[10] = c >> 16; px[11] = c >> 24;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float c0 = (float)px[k * 3 + 0] / 255.0f, c1 = (float)px[k * 3 + 1] / 255.0f, c2 = (float)px[k * 3 + 2] / 255.0f;
+      if (bgr) { float tmp = c0; c0 = c2; c2 = tmp; }
+      dst[g * 4 + k] = make_float4((c0 - m0) / s0, (c1 - m1) / s1, (c2 - m2) / s2, 0.f);
+    }
+  }
+  // tail (pixels % 4)
+  if (blockIdx.x == 0 && threadIdx.x < (pixels & 3)) {
+    const size_t i = groups * 4 + threadIdx.x;
+    float c0 = (float)src[i * 3 + 0] / 255.0f, c1 = (float)src[i * 3 + 1] / 255.0f, c2 = (float)src[i * 3 + 2] / 255.0f;
+    if (bgr) { float tmp = c0; c0 = c2; c2 = tmp; }
+    dst[i] = make_float4((c0 - m0) / s0, (c1 - m1) / s1, (c2 - m2) / s2, 0.f);
+  }
+}
+
+void launch_u8_to_nhwc4_norm(const uint8_t* src, float* dst, size_t pixels, const float mean[3],
+                             const float stdv[3], int bgr, hipStream_t s) {
+  FE_CHECK(((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 15) == 0, "u8_to_nhwc4: alignment");
+  hipLaunchKernelGGL(u8_to_nhwc4_kernel, dim3(grid_for(pixels / 4 + 1)), dim3(256), 0, s, src, (float4*)dst, pixels,
+                     mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], bgr);
+  FE_HIP(hipGetLastError());
+}
+
+// ---- layout shuffles at the C-ABI boundary (host tensors arrive NCHW like the reference's) ----------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int c, int h, int w, int cpad) {
+  const size_t total = (size_t)n * h * w * cpad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = i % cpad;
+    const size_t pix = i / cpad;
+    const size_t hw = (size_t)h * w;
+    const size_t img = pix / hw, rem = pix - img * hw;
+    dst[i] = ch < c ? src[(img * c + ch) * hw + rem] : 0.f;
+  }
+}
+void launch_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, int cpad, hipStream_t s) {
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)n * h * w * cpad)), dim3(256), 0, s, src, dst, n, c, h, w, cpad);
+  FE_HIP(hipGetLastError());
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst, int n, int c, int h, int w) {
+  const size_t total = (size_t)n * c * h * w;
+  const size_t hw = (size_t)h * w;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t rem = i % hw;
+    const size_t t = i / hw;
+    const int ch = t % c;
+    const size_t img = t / c;
+    dst[i] = src[(img * hw + rem) * ld + ch];
+  }
+}
+void launch_nhwc_to_nchw(const float* src, int ld, float* dst, int n, int c, int h, int w, hipStream_t s) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)n * c * h * w)), dim3(256), 0, s, src, ld, dst, n, c, h, w);
+  FE_HIP(hipGetLastError());
+}
+
+// ---- max pool (NHWC, implicit -inf padding; ceil_mode windows are clipped to the input) ------------
+template <int VEC>
+__global__ void maxpool_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int n, int h, int w,
+                               int c, int ho, int wo, int k, int stride, int pad) {
+  const int cv = c / VEC;
+  const size_t total = (size_t)n * ho * wo * cv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = i % cv;
+    size_t pix = i / cv;
+    const int ow = pix % wo; pix /= wo;
+    const int oh = pix % ho;
+    const size_t img = pix / ho;
+    float best[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) best[v] = -INFINITY;
+    for (int dy = 0; dy < k; ++dy) {
+      const int ih = oh * stride - pad + dy;
+      if ((unsigned)ih >= (unsigned)h) continue;
+      for (int dx = 0; dx < k; ++dx) {
+        const int iw = ow * stride - pad + dx;
+        if ((unsigned)iw >= (unsigned)w) continue;
+        const float* p = x + ((img * h + ih) * w + iw) * ldx + cg * VEC;
+        if (VEC == 4) {
+          const float4 q = *reinterpret_cast<const float4*>(p);
+          best[0] = fmaxf(best[0], q.x); best[1 % VEC] = fmaxf(best[1 % VEC], q.y);
+          best[2 % VEC] = fmaxf(best[2 % VEC], q.z); best[3 % VEC] = fmaxf(best[3 % VEC], q.w);
+        } else {
+          best[0] = fmaxf(best[0], p[0]);
+        }
+      }
+    }
+    float* o = y + ((img * ho + oh) * wo + ow) * ldy + cg * VEC;
+    if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(best[0], best[1 % VEC], best[2 % VEC], best[3 % VEC]);
+    else o[0] = best[0];
+  }
+}
+void launch_maxpool(const Tensor& x, const Tensor& y, int k, int stride, int pad, hipStream_t s) {
+  FE_CHECK(x.c == y.c && x.n == y.n, "maxpool: shape mismatch");
+  const bool v4 = (x.c % 4 == 0) && (x.ld % 4 == 0) && (y.ld % 4 == 0) && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0;
+  const size_t work = y.pixels() * (v4 ? x.c / 4 : x.c);
+  if (v4)
+    hipLaunchKernelGGL(maxpool_kernel<4>, dim3(grid_for(work)), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w, k, stride, pad);
+  else
+    hipLaunchKernelGGL(maxpool_kernel<1>, dim3(grid_for(work)), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w, k, stride, pad);
+  FE_HIP(hipGetLastError());
+}
+
+// ---- bilinear resize, align_corners=False (torch F.interpolate semantics, reference samp_net.py:59) --
+__global__ void bilinear_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int n, int h, int w,
+                                int c, int ho, int wo, float sy, float sx) {
+  const size_t total = (size_t)n * ho * wo * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = i % c;
+    size_t pix = i / c;
+    const int ow = pix % wo; pix /= wo;
+    const int oh = pix % ho;
+    const size_t img = pix / ho;
+    float fy = ((float)oh + 0.5f) * sy - 0.5f; if (fy < 0.f) fy = 0.f;
+    float fx = ((float)ow + 0.5f) * sx - 0.5f; if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* b = x + img * h * w * ldx + ch;
+    const float v00 = b[((size_t)y0 * w + x0) * ldx], v01 = b[((size_t)y0 * w + x1) * ldx];
+    const float v10 = b[((size_t)y1 * w + x0) * ldx], v11 = b[((size_t)y1 * w + x1) * ldx];
+    y[((img * ho + oh) * wo + ow) * ldy + ch] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  }
+}
+void launch_bilinear(const Tensor& x, const Tensor& y, hipStream_t s) {
+  FE_CHECK(x.c == y.c && x.n == y.n, "bilinear: shape mismatch");
+  const float sy = (float)x.h / (float)y.h, sx = (float)x.w / (float)y.w;
+  hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(y.numel())), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w, sy, sx);
+  FE_HIP(hipGetLastError());
+}
+
+// ---- adaptive average pool (torch semantics) ---------------------------------------------------------
+__global__ void adaptive_avgpool_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int n, int h,
+                                        int w, int c, int ho, int wo) {
+  const size_t total = (size_t)n * ho * wo * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = i % c;
+    size_t pix = i / c;
+    const int ow = pix % wo; pix /= wo;
+    const int oh = pix % ho;
+    const size_t img = pix / ho;
+    const int hs = (oh * h) / ho, he = ((oh + 1) * h + ho - 1) / ho;
+    const int ws = (ow * w) / wo, we = ((ow + 1) * w + wo - 1) / wo;
+    float acc = 0.f;
+    for (int iy = hs; iy < he; ++iy)
+      for (int ix = ws; ix < we; ++ix) acc += x[((img * h + iy) * w + ix) * ldx + ch];
+    y[((img * ho + oh) * wo + ow) * ldy + ch] = acc / (float)((he - hs) * (we - ws));
+  }
+}
+void launch_adaptive_avgpool(const Tensor& x, const Tensor& y, hipStream_t s) {
+  FE_CHECK(x.c == y.c && x.n == y.n, "adaptive_avgpool: shape mismatch");
+  hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(grid_for(y.numel())), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w);
+  FE_HIP(hipGetLastError());
+}
+
+// ---- elementwise ---------------------------------------------------------------------------------------
+__global__ void sigmoid_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, size_t pixels, int c) {
+  const size_t total = pixels * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / c; const int ch = i % c;
+    y[pix * ldy + ch] = 1.f / (1.f + expf(-x[pix * ldx + ch]));
+  }
+}
+void launch_sigmoid(const Tensor& x, const Tensor& y, hipStream_t s) {
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(grid_for(x.numel())), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.pixels(), x.c);
+  FE_HIP(hipGetLastError());
+}
+__global__ void add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, float* __restrict__ y,
+                           int ldy, size_t pixels, int c) {
+  const size_t total = pixels * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / c; const int ch = i % c;
+    y[pix * ldy + ch] = a[pix * lda + ch] + b[pix * ldb + ch];
+  }
+}
+void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s) {
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(a.numel())), dim3(256), 0, s, a.p, a.ld, b.p, b.ld, y.p, y.ld, a.pixels(), a.c);
+  FE_HIP(hipGetLastError());
+}
+
+// ---- LayerNorm: one wave per row, two-pass (mean, then centred variance) in registers ------------------
+__global__ void layernorm_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                 const float* __restrict__ g, const float* __restrict__ b, int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int row = wave; row < rows; row += nwaves) {
+    const float* xr = x + (size_t)row * ldx;
+    float sum = 0.f;
+    for (int i = lane; i < d; i += 64) sum += xr[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)d;
+    float var = 0.f;
+    for (int i = lane; i < d; i += 64) { const float t = xr[i] - mean; var += t * t; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)d + eps);
+    float* yr = y + (size_t)row * ldy;
+    for (int i = lane; i < d; i += 64) yr[i] = (xr[i] - mean) * rstd * g[i] + b[i];
+  }
+}
+void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int rows, int d,
+                      float eps, hipStream_t s) {
+  const int blocks = grid_for((size_t)rows * 64);
+  hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, d, eps);
+  FE_HIP(hipGetLastError());
+}
+
+// ---- row softmax, one wave per row ---------------------------------------------------------------------
+__global__ void softmax_rows_kernel(float* __restrict__ x, int ld, int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int row = wave; row < rows; row += nwaves) {
+    float* xr = x + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int i = lane; i < d; i += 64) mx = fmaxf(mx, xr[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int i = lane; i < d; i += 64) { const float e = expf(xr[i] - mx); xr[i] = e; sum += e; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+    for (int i = lane; i < d; i += 64) xr[i] *= inv;
+  }
+}
+void launch_softmax_rows(float* x, int ld, int rows, int d, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for((size_t)rows * 64)), dim3(256), 0, s, x, ld, rows, d);
+  FE_HIP(hipGetLastError());
+}
+
+}  // namespace fe

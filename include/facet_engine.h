@@ -1,0 +1,109 @@
+/*
+ * facet_engine.h — C ABI of libfacet_engine.so, the MI355X (gfx950) image-scoring engine.
+ *
+ * The reference (rlorenzo/facet) has no FFI for this path: its model layer is duck-typed Python objects
+ * that end in torch nn.Module.__call__ / onnxruntime sessions. Each entry point below
+ * names the reference call it stands behind; the facet_amd Python package is the ctypes binding that re-exposes the
+ * reference's Python signatures on top of it.
+ *
+ * Conventions
+ *   - every function returns FE_OK (0) or a negative fe_status; fe_last_error(ctx) gives the message.
+ *   - no C++ exceptions cross this boundary; no torch / numpy types appear in it.
+ *   - the caller owns every input / output buffer for the duration of the call; the engine owns
+ *     weights and workspace behind the opaque fe_ctx.
+ *   - pointers are HOST pointers unless the parameter is named d_* or `on_device` is non-zero.
+ *   - images are uint8 HWC, RGB unless a `bgr` flag says otherwise; float tensors are fp32, NCHW,
+ *     contiguous (the layouts the reference hands to its models).
+ *   - one thread at a time per ctx for fe_*_score / fe_*_encode / fe_op_* (the reference calls its
+ *     models from one "GPU thread", processing/batch_processor.py:123); lifecycle calls are mutex-guarded.
+ */
+#ifndef FACET_ENGINE_H
+#define FACET_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fe_ctx fe_ctx;
+
+enum fe_status {
+  FE_OK = 0,
+  FE_ERR_INVALID = -1,   /* bad argument / shape */
+  FE_ERR_RUNTIME = -2,   /* HIP failure or internal check */
+  FE_ERR_NOT_LOADED = -3 /* model weights not committed */
+};
+
+/* Model slots (reference names: models/model_manager.py:393-437 'topiq','clip','samp_net',...). */
+enum fe_model {
+  FE_MODEL_TOPIQ = 0,     /* pyiqa topiq_nr: ResNet-50 + CFANet head   (models/pyiqa_scorer.py:33-39,212) */
+  FE_MODEL_CLIP = 1,      /* open_clip ViT-L/14 image tower             (processing/scorer.py:508,662)     */
+  FE_MODEL_SAMP = 2,      /* SAMPNet (ResNet-18 + pattern pooling)      (models/samp_net.py:665-791)       */
+  FE_MODEL_U2NETP = 3,    /* U2-Net-P saliency                          (models/samp_net.py:258-342)       */
+  FE_MODEL_AESTHETIC = 4  /* Linear(768,256)-ReLU-Linear(256,1)         (processing/scorer.py:579-583)     */
+};
+
+enum fe_act { FE_ACT_NONE = 0, FE_ACT_RELU = 1, FE_ACT_GELU = 2, FE_ACT_SIGMOID = 3 };
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+/* Creates a context on HIP device `device` with a workspace arena of `arena_bytes`
+ * (0 = default 8 GiB). Fails (no CPU fallback) when no gfx950 device is present. */
+int fe_create(int device, size_t arena_bytes, fe_ctx** out);
+void fe_destroy(fe_ctx* ctx);
+const char* fe_last_error(fe_ctx* ctx); /* ctx may be NULL: returns the last fe_create error */
+const char* fe_version(void);
+int fe_sync(fe_ctx* ctx);
+/* images processed per engine pass inside the batched entry points (activation footprint knob) */
+int fe_set_microbatch(fe_ctx* ctx, int n);
+
+/* ---- device buffers (so callers can keep batches resident in HBM without torch) ------------- */
+int fe_dev_alloc(fe_ctx* ctx, size_t bytes, void** d_out);
+int fe_dev_free(fe_ctx* ctx, void* d_ptr);
+int fe_memcpy_h2d(fe_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int fe_memcpy_d2h(fe_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* ---- timing / profiling on the engine's own HIP stream --------------------------------------- */
+int fe_timer_start(fe_ctx* ctx);
+int fe_timer_stop(fe_ctx* ctx, float* ms_out);
+/* per-launch timing of every contraction kernel (serialises; for roofline accounting only) */
+int fe_profile_enable(fe_ctx* ctx, int on);
+int fe_profile_count(fe_ctx* ctx);
+int fe_profile_get(fe_ctx* ctx, int i, char* name, int name_cap, double* flops, double* bytes, float* ms);
+/* algorithmic FLOPs issued since the last fe_flops_reset (2*MAC of every contraction launched) */
+int fe_flops_reset(fe_ctx* ctx);
+int fe_flops_get(fe_ctx* ctx, double* flops);
+
+/* ---- weights: replaces state_dict loading inside pyiqa.create_metric / open_clip.create_model /
+ *      SAMPNet.load_state_dict (models/pyiqa_scorer.py:108, model_manager.py:140, samp_net.py:895).
+ *      Tensors are passed by their checkpoint key names in PyTorch layout. -------------------- */
+int fe_weights_begin(fe_ctx* ctx, int model);
+int fe_weights_set(fe_ctx* ctx, int model, const char* name, const float* data, const int64_t* shape, int ndim);
+int fe_weights_commit(fe_ctx* ctx, int model); /* validates, folds BN, packs for MFMA, uploads */
+int fe_model_unload(fe_ctx* ctx, int model);   /* reference: ModelManager.unload_model (model_manager.py:237) */
+int fe_model_loaded(fe_ctx* ctx, int model);   /* 1 / 0 */
+
+/* ---- single ops (parity tests and building blocks; host NCHW in/out) -------------------------- */
+/* y = act(conv2d(x, w) * scale + shift (+ res)), torch.nn.functional.conv2d semantics.
+ * scale/shift/res may be NULL. res_after_act: add the residual after the activation. */
+int fe_op_conv2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, const float* weight, int cout, int kh,
+                 int kw, const float* scale, const float* shift, const float* res, int res_after_act, int stride,
+                 int pad, int dil, int act, float* y);
+int fe_op_maxpool2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int k, int stride, int pad,
+                    int ceil_mode, float* y);
+int fe_op_bilinear(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int ho, int wo, float* y);
+int fe_op_adaptive_avgpool(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int ho, int wo, float* y);
+int fe_op_layernorm(fe_ctx* ctx, const float* x, int rows, int d, const float* g, const float* b, float eps, float* y);
+
+/* ---- TOPIQ (reference: PyIQAScorer.score_image -> self.model(t), models/pyiqa_scorer.py:197-231) */
+/* images: n x h x w x 3 uint8 RGB (all the same size, h and w multiples of 32).
+ * level 0..4 = ResNet-50 pyramid feature (stem-relu, layer1..4) returned NCHW to host `out`. */
+int fe_topiq_features(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, int level, float* out);
+/* raw MOS per image (before the reference's clamp[0,1]*10, pyiqa_scorer.py:166-195) */
+int fe_topiq_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* scores);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FACET_ENGINE_H */

@@ -1,0 +1,109 @@
+"""GPU parity of the single HIP ops (through the C ABI) against plain torch-CPU fp32."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-4  # fp32 MFMA = k-ordered fmaf chain; torch CPU sums in a different order
+
+
+def _close(a, b, rtol=RTOL):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    scale = max(np.abs(b).max(), 1e-6)
+    err = np.abs(a - b).max() / scale
+    assert err < rtol, f"max rel-to-max err {err:.3e}"
+
+
+CONV_CASES = [
+    # n, cin, h, w, cout, k, stride, pad, dil
+    (2, 64, 56, 56, 64, 1, 1, 0, 1),      # resnet 1x1 (fast path, BN=64 tile)
+    (2, 64, 56, 56, 256, 1, 1, 0, 1),     # 1x1 expand (128x128 tile)
+    (1, 64, 40, 40, 64, 3, 1, 1, 1),      # 3x3
+    (2, 128, 28, 28, 128, 3, 2, 1, 1),    # 3x3 stride 2
+    (1, 3, 64, 64, 64, 7, 2, 3, 1),       # stem: Cin 3 -> padded 4, generic path, K=196
+    (1, 256, 14, 14, 512, 1, 2, 0, 1),    # downsample 1x1 stride 2
+    (1, 16, 31, 29, 16, 3, 1, 2, 2),      # u2netp dilated, ragged spatial, Cout 16 tile
+    (1, 32, 17, 17, 16, 3, 1, 8, 8),      # dilation 8 bigger than half the map
+    (1, 64, 20, 20, 1, 3, 1, 1, 1),       # side conv Cout=1
+    (1, 6, 20, 20, 1, 1, 1, 0, 1),        # outconv Cin 6 -> padded 8
+    (3, 24, 9, 9, 40, 3, 1, 1, 1),        # Cin%16 != 0 generic path, Cout not a tile multiple
+    (1, 1296, 2, 1, 1024, (2, 1), 1, 0, 1),  # SAMP pattern conv as full-window contraction
+    (1, 2048, 1, 1, 1000, 1, 1, 0, 1),    # M = 1 (pure GEMV shape)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_matches_torch(engine, case):
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    kh, kw = (k, k) if isinstance(k, int) else k
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) / np.sqrt(cin * kh * kw)
+    ref = F.conv2d(x, wt, None, stride, pad, dil)
+    if kh != kw:
+        pytest.skip("C ABI conv op takes square kernels; non-square covered by SAMP model test")
+    got = engine.conv2d(x.numpy(), wt.numpy(), stride=stride, pad=pad, dil=dil)
+    assert got.shape == tuple(ref.shape)
+    _close(got, ref.numpy())
+
+
+def test_conv_epilogue_bn_relu_residual(engine):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 24, 24, generator=g)
+    wt = torch.randn(256, 64, 1, 1, generator=g) / 8
+    scale = torch.rand(256, generator=g) + 0.5
+    shift = torch.randn(256, generator=g)
+    res = torch.randn(2, 256, 24, 24, generator=g)
+    y = F.conv2d(x, wt) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    _close(engine.conv2d(x.numpy(), wt.numpy(), scale.numpy(), shift.numpy(), res.numpy(), act="relu"),
+           F.relu(y + res).numpy())
+    _close(engine.conv2d(x.numpy(), wt.numpy(), scale.numpy(), shift.numpy(), res.numpy(), res_after_act=True, act="relu"),
+           (F.relu(y) + res).numpy())
+    _close(engine.conv2d(x.numpy(), wt.numpy(), scale.numpy(), shift.numpy(), act="gelu"), F.gelu(y).numpy())
+    _close(engine.conv2d(x.numpy(), wt.numpy(), scale.numpy(), shift.numpy(), act="sigmoid"), torch.sigmoid(y).numpy())
+
+
+def test_conv_exact_integers(engine):
+    """A = small integers, asymmetric weights: catches any row/col or k-permutation slip exactly."""
+    x = (torch.arange(2 * 16 * 6 * 5) % 7 - 3).float().view(2, 16, 6, 5)
+    wt = ((torch.arange(48 * 16 * 9) * 5) % 11 - 5).float().view(48, 16, 3, 3)
+    ref = F.conv2d(x, wt, None, 1, 1)
+    got = engine.conv2d(x.numpy(), wt.numpy(), stride=1, pad=1)
+    assert np.array_equal(got, ref.numpy())
+
+
+@pytest.mark.parametrize("shape,k,s,p,ceil", [((2, 64, 37, 41), 3, 2, 1, False), ((1, 16, 15, 15), 2, 2, 0, True),
+                                              ((1, 16, 14, 14), 2, 2, 0, True), ((1, 1, 224, 224), 3, 2, 1, False),
+                                              ((2, 3, 7, 9), 2, 2, 0, True)])
+def test_maxpool(engine, shape, k, s, p, ceil):
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
+    ref = F.max_pool2d(x, k, s, p, ceil_mode=ceil)
+    got = engine.maxpool2d(x.numpy(), k, s, p, ceil)
+    assert got.shape == tuple(ref.shape)
+    assert np.array_equal(got, ref.numpy())
+
+
+@pytest.mark.parametrize("shape,out", [((2, 16, 7, 7), (14, 14)), ((1, 16, 4, 4), (7, 7)), ((1, 1, 56, 56), (7, 7)),
+                                       ((1, 3, 5, 9), (11, 4)), ((1, 1, 7, 7), (224, 224))])
+def test_bilinear(engine, shape, out):
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(2))
+    ref = F.interpolate(x, size=out, mode="bilinear", align_corners=False)
+    _close(engine.bilinear(x.numpy(), *out), ref.numpy(), 1e-5)
+
+
+@pytest.mark.parametrize("shape,out", [((2, 64, 64, 64), (32, 32)), ((1, 8, 7, 7), (4, 4)), ((1, 8, 7, 7), (3, 3)),
+                                       ((1, 1, 7, 7), (8, 8)), ((1, 5, 10, 6), (1, 1))])
+def test_adaptive_avgpool(engine, shape, out):
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(3))
+    ref = F.adaptive_avg_pool2d(x, out)
+    _close(engine.adaptive_avgpool(x.numpy(), *out), ref.numpy(), 1e-5)
+
+
+def test_layernorm(engine):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(300, 1024, generator=g) * 3 + 1
+    w = torch.rand(1024, generator=g) + 0.5
+    b = torch.randn(1024, generator=g)
+    _close(engine.layernorm(x.numpy(), w.numpy(), b.numpy(), 1e-5), F.layer_norm(x, (1024,), w, b, 1e-5).numpy(), 1e-5)
