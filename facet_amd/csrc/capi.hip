@@ -8,6 +8,17 @@ struct fe_ctx {
   Ctx c;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   int microbatch = 8;
+  float* d_out = nullptr;   // persistent device staging for per-image results
+  size_t d_out_cap = 0;
+  float* out_buf(size_t floats) {
+    if (floats > d_out_cap) {
+      if (d_out) (void)hipFree(d_out);
+      d_out = nullptr; d_out_cap = 0;
+      FE_HIP(hipMalloc((void**)&d_out, floats * sizeof(float)));
+      d_out_cap = floats;
+    }
+    return d_out;
+  }
 };
 
 static std::string g_create_err;
@@ -60,6 +71,7 @@ void fe_destroy(fe_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->c.stream);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  if (ctx->d_out) (void)hipFree(ctx->d_out);
   delete ctx;
 }
 
@@ -167,6 +179,7 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
     auto m = std::make_unique<TopiqModel>();
     const int blocks[4] = {3, 4, 6, 3};
     build_resnet(m->backbone, m->dw, ws, "semantic_model.", true, blocks, false);
+    if (ws.has("weight_pool.0.splitconv.weight")) build_topiq_head(*m, ws);
     ctx->c.topiq = std::move(m);
   } else {
     throw Error("fe_weights_commit: model " + std::to_string(model) + " not implemented");
@@ -330,8 +343,31 @@ int fe_topiq_features(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
 
 int fe_topiq_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* scores) {
   FE_API_BEGIN(ctx)
-  (void)rgb; (void)n; (void)h; (void)w; (void)on_device; (void)scores;
-  throw Error("fe_topiq_score: head not implemented yet");
+  Ctx& C = ctx->c;
+  if (!C.topiq || !C.topiq->has_head) { C.err = "topiq weights (backbone + head) not loaded"; return FE_ERR_NOT_LOADED; }
+  FE_CHECK(rgb && scores && n > 0 && h >= 32 && w >= 32, "bad arguments");
+  const size_t img_bytes = (size_t)h * w * 3;
+  // scores of all micro-batches accumulate in a small device buffer outside the arena; one D2H at the end
+  float* d_scores = ctx->out_buf((size_t)n);
+  {
+    for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
+      const int nb = std::min(ctx->microbatch, n - i0);
+      C.arena.reset();
+      const uint8_t* d_in;
+      if (on_device) {
+        d_in = rgb + (size_t)i0 * img_bytes;
+      } else {
+        uint8_t* d = (uint8_t*)C.arena.alloc(nb * img_bytes);
+        FE_HIP(hipMemcpyAsync(d, rgb + (size_t)i0 * img_bytes, nb * img_bytes, hipMemcpyHostToDevice, C.stream));
+        d_in = d;
+      }
+      std::vector<Tensor> feats;
+      topiq_backbone_chunk(ctx, d_in, nb, h, w, feats);
+      topiq_head_forward(C, *C.topiq, feats, d_scores + i0);
+    }
+    FE_HIP(hipMemcpyAsync(scores, d_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+    FE_HIP(hipStreamSynchronize(C.stream));
+  }
   FE_API_END(ctx)
 }
 

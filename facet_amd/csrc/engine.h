@@ -55,6 +55,25 @@ LayerNormW build_ln(DeviceWeights& dw, const WeightStore& ws, const std::string&
 
 struct Ctx;
 
+// nn.MultiheadAttention (batch_first irrelevant: tokens of one image are contiguous rows).
+struct MHAW {
+  ConvW q, k;          // projections with bias; q carries the 1/sqrt(head_dim) scaling in scale/shift
+  float* wv = nullptr; // raw [d][d] V weight: used as the A operand so the GEMM emits V^T directly
+  float* bv = nullptr; // [d] V bias, added after P.V (softmax rows sum to 1)
+  ConvW out;           // out_proj
+  int d = 0, heads = 0;
+};
+MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& prefix, int heads);
+// y[B*Lq][d] = res + out_proj(softmax(q k^T / sqrt(hd)) v); q from q_in, k/v from kv_in (rows = tokens).
+void mha_forward(Ctx& c, const MHAW& m, const float* q_in, int ldq, const float* kv_in, int ldkv, int B, int Lq,
+                 int Lk, const float* res, int ldr, float* y, int ldy);
+// y[M][N] = act(x[M][K] W^T + b) (+res)
+void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act,
+                    const float* res = nullptr, int ldr = 0);
+inline Tensor mat_view(const float* p, int rows, int cols, int ld) {
+  Tensor t; t.p = const_cast<float*>(p); t.n = 1; t.h = 1; t.w = rows; t.c = cols; t.ld = ld; return t;
+}
+
 // Runs conv on views; allocates nothing. Output spatial dims must already be set on y.
 void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, const ConvOpts& o);
 // Allocates the output from the arena with the standard conv output size.
@@ -97,10 +116,27 @@ struct Ctx {
   ~Ctx();
 };
 
+// pre-norm transformer layers of pyiqa's CFANet (DETR-style) [DEP-KNOWLEDGE]
+struct EncLayerW { MHAW attn; ConvW lin1, lin2; LayerNormW n1, n2; };
+struct DecLayerW { MHAW cross; ConvW lin1, lin2; LayerNormW n1, n2, n3; };
+struct GatedConvW { ConvW split_x1, split_x2, w0, w2, w4; };
+
 struct TopiqModel {
   DeviceWeights dw;
   ResNet backbone;
   bool has_head = false;
+  GatedConvW gate[5];
+  ConvW dim_reduce[5];
+  EncLayerW sa[5];
+  DecLayerW cross[4];
+  EncLayerW pool;
+  LayerNormW s_ln0, s_ln3;
+  ConvW s_l1, s_l4, s_l6;
+  std::vector<float> h_emb, w_emb;           // host copies [128][32] each
+  std::map<std::pair<int, int>, float*> pos; // (th,tw) -> device [th*tw][256]
 };
+void build_topiq_head(TopiqModel& m, const WeightStore& ws);
+// feats: the 5 pyramid levels for nb images; scores_dev: device [nb]
+void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<Tensor>& feats, float* scores_dev);
 
 }  // namespace fe

@@ -234,3 +234,97 @@ Tensor resnet_forward(Ctx& c, const ResNet& r, const Tensor& x, std::vector<Tens
 }
 
 }  // namespace fe
+
+// ---------------------------------------------------------------------------------------------------
+// Linear / multi-head attention on token matrices
+// ---------------------------------------------------------------------------------------------------
+namespace fe {
+
+void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act,
+                    const float* res, int ldr) {
+  Tensor xt = mat_view(x, M, w.CinPad, ldx), yt = mat_view(y, M, w.Cout, ldy);
+  ConvOpts o; o.act = act;
+  Tensor rt;
+  if (res) { rt = mat_view(res, M, w.Cout, ldr); o.res = &rt; }
+  conv_forward(c, w, xt, yt, o);
+}
+
+MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& prefix, int heads) {
+  MHAW m;
+  const HostTensor& W = ws.get(prefix + ".in_proj_weight");
+  const HostTensor& Bv = ws.get(prefix + ".in_proj_bias");
+  const int d = (int)W.shape[1];
+  FE_CHECK(W.shape[0] == 3 * d && d % heads == 0 && d % 32 == 0, "mha %s: bad in_proj shape", prefix.c_str());
+  m.d = d; m.heads = heads;
+  m.q = build_linear_rows(dw, W, nullptr, 0, d);
+  m.k = build_linear_rows(dw, W, &Bv, d, d);
+  // q = (x Wq^T + bq) * 1/sqrt(hd)  (torch.nn.functional.multi_head_attention_forward scales q after the bias)
+  const float sc = 1.0f / std::sqrt((float)(d / heads));
+  std::vector<float> qs(d, sc), qb(d);
+  for (int i = 0; i < d; ++i) qb[i] = Bv.data[i] * sc;
+  m.q.scale = dw.upload(qs);
+  m.q.shift = dw.upload(qb);
+  std::vector<float> wv(W.data.begin() + (size_t)2 * d * d, W.data.begin() + (size_t)3 * d * d);
+  std::vector<float> bv(Bv.data.begin() + 2 * d, Bv.data.begin() + 3 * d);
+  m.wv = dw.upload(wv);
+  m.bv = dw.upload(bv);
+  m.out = build_linear(dw, ws, prefix + ".out_proj", true);
+  return m;
+}
+
+static void raw_gemm(Ctx& c, ConvParams& p, double flops) {
+  p.N = 1; p.H = 1; p.W = p.M; p.Ho = 1; p.Wo = p.M;
+  p.KH = p.KW = 1; p.sh = p.sw = p.dh = p.dw = 1; p.ph = p.pw = 0;
+  p.Kp = (p.K + CONV_KALIGN - 1) / CONV_KALIGN * CONV_KALIGN;
+  p.Cin = p.K;
+  FE_CHECK(p.xs1 % 4 == 0 && p.xs2 % 4 == 0 && p.ws1 % 4 == 0 && p.ws2 % 4 == 0, "raw_gemm: batch strides must keep 16-B alignment");
+  launch_conv(p, c.stream);
+  c.flops_accum += flops;
+}
+
+void mha_forward(Ctx& c, const MHAW& m, const float* q_in, int ldq, const float* kv_in, int ldkv, int B, int Lq, int Lk,
+                 const float* res, int ldr, float* y, int ldy) {
+  const int d = m.d, H = m.heads, hd = d / H;
+  const int Lp = (Lk + 31) / 32 * 32;  // padded key count: row stride of the score matrix and of V^T
+  const size_t mark = c.arena.mark();
+  float* Q = (float*)c.arena.alloc((size_t)B * Lq * d * sizeof(float));
+  float* K = (float*)c.arena.alloc((size_t)B * Lk * d * sizeof(float));
+  float* Vt = (float*)c.arena.alloc((size_t)B * d * Lp * sizeof(float));
+  float* S = (float*)c.arena.alloc((size_t)B * H * Lq * Lp * sizeof(float));
+  float* O = (float*)c.arena.alloc((size_t)B * Lq * d * sizeof(float));
+  linear_forward(c, m.q, q_in, ldq, B * Lq, Q, d, ACT_NONE);
+  linear_forward(c, m.k, kv_in, ldkv, B * Lk, K, d, ACT_NONE);
+  if (Lp != Lk) FE_HIP(hipMemsetAsync(Vt, 0, (size_t)B * d * Lp * sizeof(float), c.stream));
+  {  // V^T[b] [d][Lk] = Wv [d][d] . X_b^T : the token matrix plays the weight operand
+    ConvParams p{};
+    p.x = m.wv; p.ldx = d; p.w = kv_in; p.ldw = ldkv; p.y = Vt; p.ldy = Lp;
+    p.M = d; p.K = d; p.Cout = Lk;
+    p.batch = B; p.nb1 = 1; p.ws2 = (long long)Lk * ldkv; p.ys2 = (long long)d * Lp;
+    raw_gemm(c, p, 2.0 * B * d * (double)d * Lk);
+  }
+  {  // S[b,h] [Lq][Lk] = Q_bh K_bh^T
+    ConvParams p{};
+    p.x = Q; p.ldx = d; p.w = K; p.ldw = d; p.y = S; p.ldy = Lp;
+    p.M = Lq; p.K = hd; p.Cout = Lk;
+    p.batch = B * H; p.nb1 = H;
+    p.xs1 = hd; p.xs2 = (long long)Lq * d; p.ws1 = hd; p.ws2 = (long long)Lk * d;
+    p.ys1 = (long long)Lq * Lp; p.ys2 = (long long)H * Lq * Lp;
+    raw_gemm(c, p, 2.0 * B * H * (double)Lq * Lk * hd);
+  }
+  launch_softmax_rows_pad(S, Lp, B * H * Lq, Lk, c.stream);
+  {  // O[b][:, h*hd:(h+1)*hd] = P_bh V_bh + bv_h
+    ConvParams p{};
+    p.x = S; p.ldx = Lp; p.w = Vt; p.ldw = Lp; p.y = O; p.ldy = d;
+    p.shift = m.bv; p.hs1 = hd;
+    p.M = Lq; p.K = Lp; p.Cout = hd;
+    p.batch = B * H; p.nb1 = H;
+    p.xs1 = (long long)Lq * Lp; p.xs2 = (long long)H * Lq * Lp;
+    p.ws1 = (long long)hd * Lp; p.ws2 = (long long)d * Lp;
+    p.ys1 = hd; p.ys2 = (long long)Lq * d;
+    raw_gemm(c, p, 2.0 * B * H * (double)Lq * Lk * hd);
+  }
+  linear_forward(c, m.out, O, d, B * Lq, y, ldy, ACT_NONE, res, ldr);
+  c.arena.rewind(mark);
+}
+
+}  // namespace fe

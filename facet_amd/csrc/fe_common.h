@@ -113,6 +113,11 @@ struct ConvParams {
   int act;                          // Act
   int res_after_act;                // 1: y = act(conv*scale+shift) + res ; 0: y = act(conv*scale+shift+res)
   int gate_c1;                      // 1: gate has one channel (broadcast over Cout)
+  int vec_epi;                      // set by launch_conv: 16-B vector epilogue is legal
+  int ldw;                          // weight row stride in floats (0 => Kp); lets an activation matrix act as B
+  // batched launches (gridDim.y = batch): b = bo*nb1 + bi; pointer += bo*s2 + bi*s1 (element strides)
+  int batch, nb1;
+  long long xs1, xs2, ws1, ws2, ys1, ys2, hs1;   // hs1: shift stride per inner index
 };
 
 // Packed conv weight living in HBM.
@@ -161,5 +166,9 @@ void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g
                       int rows, int d, float eps, hipStream_t s);
 // rows softmax in place for [rows][d]
 void launch_softmax_rows(float* x, int ld, int rows, int d, hipStream_t s);
+// same, and zero-fills columns [d, ld) so the padded tail contributes nothing to P.V
+void launch_softmax_rows_pad(float* x, int ld, int rows, int d, hipStream_t s);
+// y[rows][d] += pos[(row % L)][d]
+void launch_add_rows_bcast(float* y, int ldy, const float* pos, int rows, int L, int d, hipStream_t s);
 
 }  // namespace fe

@@ -29,7 +29,14 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 template <int WGM, int WGN, int TM, int TN, int BK, bool FAST>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, const int ntiles) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, const int ntiles) {
+  if (p.batch > 1) {
+    const int b = blockIdx.y, bo = b / p.nb1, bi = b - bo * p.nb1;
+    p.x += bo * p.xs2 + bi * p.xs1;
+    p.w += bo * p.ws2 + bi * p.ws1;
+    p.y += bo * p.ys2 + bi * p.ys1;
+    if (p.shift) p.shift += bi * p.hs1;
+  }
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int S = BK + 4;        // LDS row stride (floats)
   constexpr int CH = BK / 4;       // 16-B chunks per row
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, con
     const int row = srow + i * RPP;
     const int n = n0 + row;
     nval[i] = (row < BN) && (n < p.Cout);
-    wrow[i] = p.w + (size_t)(nval[i] ? n : 0) * p.Kp + chunk * 4;
+    wrow[i] = p.w + (size_t)(nval[i] ? n : 0) * p.ldw + chunk * 4;
   }
 
   float4 ra[AP], rb[BP];
@@ -174,7 +181,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, con
     __syncthreads();
   }
 
-  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
+  // ---- epilogue -----------------------------------------------------------------------------------
+  // C/D map of a 32x32 tile: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+  // Vector path: each wave transposes its accumulators through a private LDS region (the staging buffers
+  // are dead after the last barrier) so that global traffic is 16 B per lane over whole 128/256-B row
+  // segments: residual loads are issued 8 deep before any use, stores are full float4.
+  const bool vec_ok = p.vec_epi;
+  if (vec_ok) {
+    constexpr int WC = TN * 32;          // wave tile width (floats)
+    constexpr int ES = WC + 4;           // LDS row stride
+    constexpr int LPR = WC / 4;          // lanes per row (16-B each)
+    constexpr int RPI = 64 / LPR;        // rows per wave instruction
+    constexpr int NIT = 32 / RPI;        // instructions per 32-row slab
+    static_assert(4 * 32 * ES <= 2 * (BM + BN) * S, "epilogue staging must fit in the k-slab buffers");
+    float* E = smem + wave * 32 * ES;
+    const int lr = lane / LPR, lc = (lane % LPR) * 4;
+    const int colb = n0 + wn * WC + lc;
+    const bool cok = colb < p.Cout;      // Cout % 4 == 0 on this path
+    const int colc = cok ? colb : 0;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + colc);
+    if (p.shift) sf = *reinterpret_cast<const float4*>(p.shift + colc);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
+      const int mrow0 = m0 + wm * TM * 32 + i * 32 + lr;
+      float4 rv[NIT], gv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = mrow0 + it * RPI;
+        const int mc = m < p.M ? m : p.M - 1;
+        if (p.res) rv[it] = *reinterpret_cast<const float4*>(p.res + (size_t)mc * p.ldr + colc);
+        if (p.gate) {
+          if (p.gate_c1) { const float g = p.gate[(size_t)mc * p.ldg]; gv[it] = make_float4(g, g, g, g); }
+          else gv[it] = *reinterpret_cast<const float4*>(p.gate + (size_t)mc * p.ldg + colc);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = mrow0 + it * RPI;
+        float4 v = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc]);
+        v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+        if (p.res && !p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+        v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+        if (p.res && p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+        if (p.gate) { v.x *= gv[it].x; v.y *= gv[it].y; v.z *= gv[it].z; v.w *= gv[it].w; }
+        if (cok && m < p.M) *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + colb) = v;
+      }
+    }
+    return;
+  }
+  // Scalar path (Cout or a channel stride not a multiple of 4): rare, small layers only.
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * TN * 32 + j * 32 + r;
@@ -211,7 +271,7 @@ static void launch_variant(const ConvParams& p, hipStream_t s) {
     FE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, s, p, ntiles);
+  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, ntiles);
   FE_HIP(hipGetLastError());
 }
 
@@ -223,17 +283,27 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
   FE_CHECK(p.Kp % CONV_KALIGN == 0 && p.Kp >= p.K, "conv: bad Kp=%d K=%d", p.Kp, p.K);
   FE_CHECK(p.M > 0 && p.Cout > 0, "conv: empty problem");
   FE_CHECK((long long)p.N * p.H * p.W < (1ll << 31), "conv: too many input pixels");
+  ConvParams q = p;
+  if (q.ldw == 0) q.ldw = q.Kp;
+  if (q.batch < 1) q.batch = 1;
+  if (q.nb1 < 1) q.nb1 = 1;
+  FE_CHECK(q.ldw % 4 == 0, "conv: ldw=%d must be a multiple of 4", q.ldw);
+  FE_CHECK(q.batch == 1 || (!q.res && !q.gate && !q.scale), "conv: batched launches take no res/gate/scale");
+  auto al16 = [](const void* ptr) { return ((uintptr_t)ptr & 15) == 0; };
+  q.vec_epi = (p.Cout % 4 == 0) && (p.ldy % 4 == 0) && al16(p.y) && (!p.res || (p.ldr % 4 == 0 && al16(p.res))) &&
+              (!p.gate || p.gate_c1 || (p.ldg % 4 == 0 && al16(p.gate))) && (!p.scale || al16(p.scale)) &&
+              (!p.shift || (al16(p.shift) && p.hs1 % 4 == 0)) && (p.batch <= 1 || (p.ys1 % 4 == 0 && p.ys2 % 4 == 0));
   const bool fast = (p.Cin % 16 == 0);
   // Tile choice: wide-N tiles for Cout >= 128, tall tiles for narrow outputs.
   if (p.Cout > 64) {
-    if (fast) launch_variant<2, 2, 2, 2, 16, true>(p, s);
-    else launch_variant<2, 2, 2, 2, 16, false>(p, s);
+    if (fast) launch_variant<2, 2, 2, 2, 16, true>(q, s);
+    else launch_variant<2, 2, 2, 2, 16, false>(q, s);
   } else if (p.Cout > 32) {
-    if (fast) launch_variant<4, 1, 2, 2, 16, true>(p, s);
-    else launch_variant<4, 1, 2, 2, 16, false>(p, s);
+    if (fast) launch_variant<4, 1, 2, 2, 16, true>(q, s);
+    else launch_variant<4, 1, 2, 2, 16, false>(q, s);
   } else {
-    if (fast) launch_variant<4, 1, 2, 1, 16, true>(p, s);
-    else launch_variant<4, 1, 2, 1, 16, false>(p, s);
+    if (fast) launch_variant<4, 1, 2, 1, 16, true>(q, s);
+    else launch_variant<4, 1, 2, 1, 16, false>(q, s);
   }
 }
 

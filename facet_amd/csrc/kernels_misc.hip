@@ -254,6 +254,39 @@ __global__ void softmax_rows_kernel(float* __restrict__ x, int ld, int rows, int
     for (int i = lane; i < d; i += 64) xr[i] *= inv;
   }
 }
+__global__ void softmax_rows_pad_kernel(float* __restrict__ x, int ld, int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int row = wave; row < rows; row += nwaves) {
+    float* xr = x + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int i = lane; i < d; i += 64) mx = fmaxf(mx, xr[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int i = lane; i < d; i += 64) { const float e = expf(xr[i] - mx); xr[i] = e; sum += e; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+    for (int i = lane; i < ld; i += 64) xr[i] = i < d ? xr[i] * inv : 0.f;
+  }
+}
+void launch_softmax_rows_pad(float* x, int ld, int rows, int d, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_rows_pad_kernel, dim3(grid_for((size_t)rows * 64)), dim3(256), 0, s, x, ld, rows, d);
+  FE_HIP(hipGetLastError());
+}
+__global__ void add_rows_bcast_kernel(float* __restrict__ y, int ldy, const float* __restrict__ pos, size_t rows, int L, int d) {
+  const size_t total = rows * d;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / d; const int ch = i % d;
+    y[row * ldy + ch] += pos[(row % L) * d + ch];
+  }
+}
+void launch_add_rows_bcast(float* y, int ldy, const float* pos, int rows, int L, int d, hipStream_t s) {
+  hipLaunchKernelGGL(add_rows_bcast_kernel, dim3(grid_for((size_t)rows * d)), dim3(256), 0, s, y, ldy, pos, (size_t)rows, L, d);
+  FE_HIP(hipGetLastError());
+}
 void launch_softmax_rows(float* x, int ld, int rows, int d, hipStream_t s) {
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for((size_t)rows * 64)), dim3(256), 0, s, x, ld, rows, d);
   FE_HIP(hipGetLastError());

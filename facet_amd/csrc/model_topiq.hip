@@ -1,0 +1,203 @@
+// TOPIQ-NR head (pyiqa CFANet on a ResNet-50 pyramid): gated local pooling, per-level self-attention,
+// coarse-to-fine cross-attention, attention pooling and the MOS MLP.
+//
+// Stands behind reference models/pyiqa_scorer.py:212 (`self.model(t)`, pyiqa `topiq_nr`). The arithmetic is
+// pyiqa's, which is not vendored in the reference: this follows the published CFANet definition
+// (use_ref=False, inter_dim=256, 4 heads, 1 layer per block, GELU, pre-norm) [DEP-KNOWLEDGE] and is
+// parity-checked against oracle/topiq.py, the same restatement in torch-CPU ("parity unpinned").
+#include "engine.h"
+#include <cmath>
+
+namespace fe {
+
+static EncLayerW build_enc(DeviceWeights& dw, const WeightStore& ws, const std::string& p, int heads) {
+  EncLayerW e;
+  e.attn = build_mha(dw, ws, p + ".self_attn", heads);
+  e.lin1 = build_linear(dw, ws, p + ".linear1", true);
+  e.lin2 = build_linear(dw, ws, p + ".linear2", true);
+  e.n1 = build_ln(dw, ws, p + ".norm1");
+  e.n2 = build_ln(dw, ws, p + ".norm2");
+  return e;
+}
+
+static DecLayerW build_dec(DeviceWeights& dw, const WeightStore& ws, const std::string& p, int heads) {
+  DecLayerW d;
+  d.cross = build_mha(dw, ws, p + ".multihead_attn", heads);
+  d.lin1 = build_linear(dw, ws, p + ".linear1", true);
+  d.lin2 = build_linear(dw, ws, p + ".linear2", true);
+  d.n1 = build_ln(dw, ws, p + ".norm1");
+  d.n2 = build_ln(dw, ws, p + ".norm2");
+  d.n3 = build_ln(dw, ws, p + ".norm3");
+  return d;
+}
+
+void build_topiq_head(TopiqModel& m, const WeightStore& ws) {
+  const int heads = 4;
+  for (int i = 0; i < 5; ++i) {
+    const std::string g = "weight_pool." + std::to_string(i);
+    // splitconv: Conv2d(dim, 2*dim, 1); chunk(2, dim=1) -> x1 = rows [0,dim), x2 = rows [dim, 2dim)
+    const HostTensor& W = ws.get(g + ".splitconv.weight");
+    const HostTensor& B = ws.get(g + ".splitconv.bias");
+    const int dim = (int)W.shape[1];
+    FE_CHECK(W.shape[0] == 2 * dim, "splitconv %d shape", i);
+    HostTensor W2; W2.shape = {2 * dim, dim}; W2.data = W.data;  // [2dim][dim][1][1] == [2dim][dim]
+    m.gate[i].split_x1 = build_linear_rows(m.dw, W2, &B, 0, dim);
+    m.gate[i].split_x2 = build_linear_rows(m.dw, W2, &B, dim, dim);
+    m.gate[i].w0 = build_conv(m.dw, ws, g + ".weight_blk.0", "", true);
+    m.gate[i].w2 = build_conv(m.dw, ws, g + ".weight_blk.2", "", true);
+    m.gate[i].w4 = build_conv(m.dw, ws, g + ".weight_blk.4", "", true);
+    m.dim_reduce[i] = build_conv(m.dw, ws, "dim_reduce." + std::to_string(i) + ".0", "", true);
+    m.sa[i] = build_enc(m.dw, ws, "sa_attn_blks." + std::to_string(i) + ".layers.0", heads);
+  }
+  for (int i = 0; i < 4; ++i) m.cross[i] = build_dec(m.dw, ws, "attn_blks." + std::to_string(i) + ".layers.0", heads);
+  m.pool = build_enc(m.dw, ws, "attn_pool", heads);
+  m.s_ln0 = build_ln(m.dw, ws, "score_linear.0");
+  m.s_l1 = build_linear(m.dw, ws, "score_linear.1", true);
+  m.s_ln3 = build_ln(m.dw, ws, "score_linear.3");
+  m.s_l4 = build_linear(m.dw, ws, "score_linear.4", true);
+  m.s_l6 = build_linear(m.dw, ws, "score_linear.6", true);
+  m.h_emb = ws.get("h_emb").data;  // [1][128][32][1]
+  m.w_emb = ws.get("w_emb").data;  // [1][128][1][32]
+  FE_CHECK(m.h_emb.size() == 128 * 32 && m.w_emb.size() == 128 * 32, "pos emb size");
+  m.has_head = true;
+}
+
+// torch upsample_bicubic2d (A=-0.75, align_corners=False): taps i-1..i+2 around floor(src), clamped.
+static void cubic_taps(int out, int in, int o, int idx[4], float wt[4]) {
+  const float scale = (float)in / (float)out;
+  const float real = scale * ((float)o + 0.5f) - 0.5f;
+  const float fl = std::floor(real);
+  const float t = real - fl;
+  const int i0 = (int)fl;
+  const float A = -0.75f;
+  auto c1 = [&](float x) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; };
+  auto c2 = [&](float x) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; };
+  wt[0] = c2(t + 1.f); wt[1] = c1(t); wt[2] = c1(1.f - t); wt[3] = c2(2.f - t);
+  for (int k = 0; k < 4; ++k) {
+    int j = i0 - 1 + k;
+    idx[k] = j < 0 ? 0 : (j > in - 1 ? in - 1 : j);
+  }
+}
+
+// pos[(y*tw + x)][c]: channels 0..127 from h_emb (varies with y), 128..255 from w_emb (varies with x).
+static float* topiq_pos(TopiqModel& m, int th, int tw) {
+  auto key = std::make_pair(th, tw);
+  auto it = m.pos.find(key);
+  if (it != m.pos.end()) return it->second;
+  std::vector<float> hy((size_t)th * 128), wx((size_t)tw * 128);
+  int idx[4]; float wt[4];
+  for (int y = 0; y < th; ++y) {
+    cubic_taps(th, 32, y, idx, wt);
+    for (int c = 0; c < 128; ++c) {
+      float acc = 0.f;
+      for (int k = 0; k < 4; ++k) acc += wt[k] * m.h_emb[(size_t)c * 32 + idx[k]];
+      hy[(size_t)y * 128 + c] = acc;
+    }
+  }
+  for (int x = 0; x < tw; ++x) {
+    cubic_taps(tw, 32, x, idx, wt);
+    for (int c = 0; c < 128; ++c) {
+      float acc = 0.f;
+      for (int k = 0; k < 4; ++k) acc += wt[k] * m.w_emb[(size_t)c * 32 + idx[k]];
+      wx[(size_t)x * 128 + c] = acc;
+    }
+  }
+  std::vector<float> pos((size_t)th * tw * 256);
+  for (int y = 0; y < th; ++y)
+    for (int x = 0; x < tw; ++x) {
+      float* d = &pos[((size_t)y * tw + x) * 256];
+      for (int c = 0; c < 128; ++c) { d[c] = hy[(size_t)y * 128 + c]; d[128 + c] = wx[(size_t)x * 128 + c]; }
+    }
+  float* dev = m.dw.upload(pos);
+  m.pos[key] = dev;
+  return dev;
+}
+
+static void ln(Ctx& c, const LayerNormW& l, const float* x, float* y, int rows) {
+  launch_layernorm(x, l.d, y, l.d, l.g, l.b, rows, l.d, l.eps, c.stream);
+}
+
+// x, y: [B*L][d]; y may alias x. Pre-norm encoder layer (q = k = v = norm1(x)).
+static void enc_forward(Ctx& c, const EncLayerW& e, float* x, float* y, int B, int L) {
+  const int d = e.n1.d, rows = B * L, ff = e.lin1.Cout;
+  const size_t mark = c.arena.mark();
+  float* n = (float*)c.arena.alloc((size_t)rows * d * sizeof(float));
+  float* a = (float*)c.arena.alloc((size_t)rows * d * sizeof(float));
+  float* hbuf = (float*)c.arena.alloc((size_t)rows * ff * sizeof(float));
+  ln(c, e.n1, x, n, rows);
+  mha_forward(c, e.attn, n, d, n, d, B, L, L, x, d, a, d);
+  ln(c, e.n2, a, n, rows);
+  linear_forward(c, e.lin1, n, d, rows, hbuf, ff, ACT_GELU);
+  linear_forward(c, e.lin2, hbuf, ff, rows, y, d, ACT_NONE, a, d);
+  c.arena.rewind(mark);
+}
+
+// tgt: [B*Lq][d] (updated in place), memory: [B*Lk][d]
+static void dec_forward(Ctx& c, const DecLayerW& w, float* tgt, const float* memory, int B, int Lq, int Lk) {
+  const int d = w.n1.d, ff = w.lin1.Cout;
+  const size_t mark = c.arena.mark();
+  float* mem = (float*)c.arena.alloc((size_t)B * Lk * d * sizeof(float));
+  float* t2 = (float*)c.arena.alloc((size_t)B * Lq * d * sizeof(float));
+  float* a = (float*)c.arena.alloc((size_t)B * Lq * d * sizeof(float));
+  float* hbuf = (float*)c.arena.alloc((size_t)B * Lq * ff * sizeof(float));
+  ln(c, w.n2, memory, mem, B * Lk);
+  ln(c, w.n1, tgt, t2, B * Lq);
+  mha_forward(c, w.cross, t2, d, mem, d, B, Lq, Lk, tgt, d, a, d);
+  ln(c, w.n3, a, t2, B * Lq);
+  linear_forward(c, w.lin1, t2, d, B * Lq, hbuf, ff, ACT_GELU);
+  linear_forward(c, w.lin2, hbuf, ff, B * Lq, tgt, d, ACT_NONE, a, d);
+  c.arena.rewind(mark);
+}
+
+void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<Tensor>& feats, float* scores_dev) {
+  FE_CHECK(m.has_head && feats.size() == 5, "topiq head: not built / bad pyramid");
+  const int B = feats[0].n;
+  const int th = feats[4].h, tw = feats[4].w, L = th * tw, d = 256;
+  const float* pos = topiq_pos(m, th, tw);
+  float* tok[5];
+  for (int i = 0; i < 5; ++i) tok[i] = (float*)c.arena.alloc((size_t)B * L * d * sizeof(float));
+  for (int i = 4; i >= 0; --i) {
+    const size_t mark = c.arena.mark();
+    const Tensor& f = feats[i];
+    const GatedConvW& g = m.gate[i];
+    ConvOpts plain;
+    Tensor x2 = conv_new(c, g.split_x2, f, plain);
+    ConvOpts o0; o0.act = ACT_GELU;
+    Tensor wa = conv_new(c, g.w0, x2, o0);
+    ConvOpts o2; o2.act = ACT_GELU; o2.ph = o2.pw = 1;
+    Tensor wb = conv_new(c, g.w2, wa, o2);
+    ConvOpts o4; o4.act = ACT_SIGMOID; o4.ph = o4.pw = 1;
+    Tensor wc = conv_new(c, g.w4, wb, o4);
+    ConvOpts og; og.act = ACT_GELU; og.gate = &wc;   // gelu(x1) * weight
+    Tensor gated = conv_new(c, g.split_x1, f, og);
+    if (gated.h > th && gated.w > tw) {
+      Tensor pooled = c.arena.tensor(B, th, tw, gated.c);
+      launch_adaptive_avgpool(gated, pooled, c.stream);
+      gated = pooled;
+    }
+    FE_CHECK(gated.h == th && gated.w == tw, "topiq head: level %d is %dx%d, expected %dx%d", i, gated.h, gated.w, th, tw);
+    Tensor t = mat_view(tok[i], B * L, d, d);
+    t.n = B; t.h = th; t.w = tw;
+    ConvOpts od; od.act = ACT_GELU;
+    conv_forward(c, m.dim_reduce[i], gated, t, od);
+    launch_add_rows_bcast(tok[i], d, pos, B * L, L, d, c.stream);
+    enc_forward(c, m.sa[i], tok[i], tok[i], B, L);
+    c.arena.rewind(mark);
+  }
+  float* query = tok[4];
+  for (int i = 0; i < 4; ++i) dec_forward(c, m.cross[i], query, tok[3 - i], B, L, L);
+  enc_forward(c, m.pool, query, query, B, L);
+  // mean over tokens, then the MOS MLP
+  Tensor fin; fin.p = query; fin.n = B; fin.h = 1; fin.w = L; fin.c = d; fin.ld = d;
+  Tensor mean = c.arena.tensor(B, 1, 1, d);
+  launch_adaptive_avgpool(fin, mean, c.stream);
+  float* a = (float*)c.arena.alloc((size_t)B * d * sizeof(float));
+  float* b = (float*)c.arena.alloc((size_t)B * d * sizeof(float));
+  ln(c, m.s_ln0, mean.p, a, B);
+  linear_forward(c, m.s_l1, a, d, B, b, d, ACT_GELU);
+  ln(c, m.s_ln3, b, a, B);
+  linear_forward(c, m.s_l4, a, d, B, b, d, ACT_GELU);
+  linear_forward(c, m.s_l6, b, d, B, scores_dev, 1, ACT_NONE);
+}
+
+}  // namespace fe

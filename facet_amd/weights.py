@@ -82,7 +82,7 @@ def _enc_layer(spec, name, d, ff):
 
 
 def _dec_layer(spec, name, d, ff):
-    _mha(spec, name + ".self_attn", d)
+    # (pyiqa's decoder layer also owns an unused `self_attn`; its forward is cross-attention only)
     _mha(spec, name + ".multihead_attn", d)
     _linear(spec, name + ".linear1", ff, d)
     _linear(spec, name + ".linear2", d, ff)

@@ -45,3 +45,37 @@ def test_resnet50_pyramid(engine, topiq_loaded, hw):
         assert got.shape == r.shape
         err = np.abs(got - r).max() / np.abs(r).max()
         assert err < 1e-3, f"level {level}: {err:.3e}"
+
+
+def _oracle_scores(sd, imgs):
+    from oracle.topiq import CFANet
+    net = CFANet().eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    x = torch.from_numpy(imgs.astype(np.float32) / 255.0).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        return net(x).flatten().numpy()
+
+
+@pytest.mark.parametrize("hw,n", [((128, 160), 3), ((224, 224), 2), ((256, 320), 2)])
+def test_topiq_score_matches_oracle(engine, topiq_loaded, hw, n):
+    """Raw MOS within 1e-3 relative of the oracle (north_star tolerance), ragged micro-batches, odd token counts
+    (224 -> 7x7 = 49 tokens exercises the padded-key attention path)."""
+    imgs = synthetic_images(5, n, *hw)
+    ref = _oracle_scores(topiq_loaded, imgs)
+    engine.set_microbatch(2)
+    got = engine.topiq_score(imgs)
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
+    assert rel.max() < 1e-3, f"got {got} ref {ref} rel {rel}"
+
+
+def test_topiq_device_resident_input_and_batch_invariance(engine, topiq_loaded):
+    """Same scores whether images arrive from host or are resident in HBM, and independent of micro-batching."""
+    imgs = synthetic_images(6, 5, 128, 128)
+    engine.set_microbatch(5)
+    a = engine.topiq_score(imgs)
+    d = engine.dev_alloc(imgs.nbytes)
+    engine.h2d(d, imgs)
+    engine.set_microbatch(2)
+    b = engine.topiq_score((d, 5, 128, 128))
+    engine.dev_free(d)
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
