@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of the scoring hot path on synthetic 1024x1024 RGB batches.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
+   one rank per GPU, images sharded independently, per-image scores all-gathered over RCCL each step)
+
+A "step" = one pass of the hot path over one batch resident in HBM. The N=1 workload is BASELINE.json
+configs[1]: TOPIQ (ResNet-50 pyramid + CFANet head) fp32, batch 256, 1024x1024, synthetic checkpoint
+(facet_amd.weights, seed 3) and synthetic uint8 images. Per-GPU work is fixed as N grows
+(weak scaling); `value` = images all ranks scored / max-over-ranks wall time.
+
+Prints ONE JSON line (rank 0) with `roofline` (fp32-MFMA bound; achieved = algorithmic FLOPs of the timed
+region / HIP-event time on the engine stream) and `cpu_baseline` (torch-CPU oracle port on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "images/sec whole-node (TOPIQ+SAMP+CLIP+InsightFace ensemble), 1024² batch"
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def cpu_baseline(sample, hw, seed_w):
+    """Oracle (torch-CPU fp32 port of TOPIQ) on a bounded sample, one image per forward like the reference's
+    PyIQAScorer.score_batch loop (models/pyiqa_scorer.py:245-253)."""
+    import torch
+    from facet_amd.weights import synthetic_state_dict, synthetic_images
+    from oracle.topiq import CFANet
+    net = CFANet().eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict("topiq", seed_w).items()})
+    imgs = synthetic_images(2, sample, hw, hw)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        x = torch.from_numpy(imgs[:1].astype(np.float32) / 255.0).permute(0, 3, 1, 2)
+        net(x)  # warm
+        t0 = time.perf_counter()
+        for i in range(sample):
+            x = torch.from_numpy(imgs[i:i + 1].astype(np.float32) / 255.0).permute(0, 3, 1, 2)
+            net(x)
+        dt = time.perf_counter() - t0
+    return {"value": round(sample / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{sample} x {hw}x{hw} synthetic RGB through oracle/topiq.py CFANet (torch {torch.__version__} CPU "
+                      f"fp32, {cores} threads, one image per forward)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--microbatch", type=int, default=8)
+    ap.add_argument("--cpu-sample", type=int, default=4, help="images for the CPU baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from facet_amd import Engine
+    from facet_amd._lib import FE_MODEL_TOPIQ
+    from facet_amd.weights import synthetic_state_dict
+    from facet_amd.sharding import shard_range, gather_scores
+
+    B, HW = args.batch, args.size
+    eng = Engine(local_rank, arena_bytes=(4 + 2 * args.microbatch) << 30)
+    eng.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", seed=3))
+    eng.set_microbatch(args.microbatch)
+
+    # this rank's shard of the global batch (weak scaling: B images per GPU), generated once, resident in HBM
+    lo, hi = shard_range(B * world, world, rank)
+    rng = np.random.default_rng([2, rank])
+    d_imgs = eng.dev_alloc(B * HW * HW * 3)
+    chunk = 32
+    import ctypes
+    for i in range(0, B, chunk):
+        nb = min(chunk, B - i)
+        a = rng.integers(0, 256, (nb, HW, HW, 3), dtype=np.uint8)
+        eng.h2d(ctypes.c_void_p(d_imgs.value + i * HW * HW * 3), a)
+    images = (d_imgs, B, HW, HW)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        scores = eng.topiq_score(images)
+        return gather_scores(scores, world, local_rank)
+
+    for _ in range(args.warmup):
+        step()
+    eng.flops_reset()
+    barrier()
+    eng.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        allscores = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = eng.timer_stop()
+    flops = eng.flops()
+    assert allscores.shape == (B * world,) and np.isfinite(allscores).all()
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    if rank == 0:
+        total_images = B * world * args.steps
+        achieved = flops / (ev_ms * 1e-3) / 1e12
+        out = {
+            "metric": METRIC, "value": round(total_images / dt_max, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"TOPIQ-NR (ResNet-50 pyramid + CFANet head) fp32, batch {B}/GPU, {HW}x{HW} RGB "
+                                   "(BASELINE.json configs[1])",
+                       "global_batch": B * world, "image_size": HW, "microbatch": args.microbatch,
+                       "parallelism": f"image-sharded x{world}, RCCL all-gather of scores",
+                       "weights": "seeded synthetic checkpoint (no weight files offline)"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM, all launches of the step)",
+                         "flops_per_image": round(flops / (B * args.steps), 1),
+                         "event_ms": round(ev_ms, 3)},
+        }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, HW, 3)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.dev_free(d_imgs)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
