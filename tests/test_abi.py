@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads, exports every symbol include/facet_engine.h declares, and the ctypes table
+matches the header. No compute calls (there is no GPU here) — and creating a context must fail loudly."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "facet_engine.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fe_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from facet_amd._lib import load_library, SIGNATURES
+    lib = load_library()
+    declared = _header_functions()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in facet_engine.h but not exported"
+        assert name in SIGNATURES, f"{name} has no ctypes signature in facet_amd/_lib.py"
+    for name in SIGNATURES:
+        assert name in declared, f"{name} bound in _lib.py but not declared in the header"
+
+
+def test_version_string():
+    from facet_amd._lib import load_library
+    assert b"gfx950" in load_library().fe_version()
+
+
+def test_no_silent_cpu_fallback():
+    """Without a gfx950 device fe_create must fail with a message, never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from facet_amd import Engine, EngineError
+    with pytest.raises(EngineError, match="no HIP device|not .*gfx950|fe_create failed"):
+        Engine(0)
+
+
+def test_product_package_does_not_import_oracle():
+    """facet_amd/ (the shipped path) must never import oracle/ (test infrastructure)."""
+    pkg = os.path.join(ROOT, "facet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports oracle"

@@ -1,0 +1,66 @@
+"""CPU: the N>1 path — contiguous image shards + one all-gather of per-image records — over gloo, world_size 2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from facet_amd.sharding import shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 100000, 256 * 8 + 3):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_items, q):
+    import torch.distributed as dist
+    from facet_amd.sharding import shard_range, gather_scores, gather_ragged
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # equal shards: per-image record = (global index, index^2)
+        lo, hi = shard_range(8, world, rank)
+        rec = np.stack([np.arange(lo, hi), np.arange(lo, hi) ** 2], 1).astype(np.float32)
+        full = gather_scores(rec, world)
+        ok1 = full.shape == (8, 2) and np.array_equal(full[:, 0], np.arange(8)) and np.array_equal(full[:, 1], np.arange(8) ** 2)
+        # ragged shards
+        lo, hi = shard_range(n_items, world, rank)
+        local = np.arange(lo, hi, dtype=np.float32) * 0.5
+        allv = gather_ragged(local, n_items, world, rank)
+        ok2 = np.array_equal(allv, np.arange(n_items, dtype=np.float32) * 0.5)
+        q.put((rank, bool(ok1), bool(ok2)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [7, 10])
+def test_allgather_world2_gloo(n_items):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True, True), (1, True, True)]
