@@ -65,6 +65,8 @@ SIGNATURES = {
     "fe_op_layernorm": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_float, _f32p]),
     "fe_topiq_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_topiq_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
+    "fe_u2netp_saliency": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
+    "fe_samp_forward": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p]),
 }
 
 
@@ -280,3 +282,27 @@ class Engine:
         y = np.empty((n,), np.float32)
         self._ck(self.lib.fe_topiq_score(self.h, p, n, h, w, dev, y.ctypes.data_as(_f32p)))
         return y
+
+    # -- U2-Net-P + SAMP-Net ------------------------------------------------------------------
+    def u2netp_saliency(self, x):
+        """x: float32 [n,3,h,w] normalised -> saliency [n,1,h,w]."""
+        x, xp = _f32(x)
+        n, c, h, w = x.shape
+        assert c == 3
+        y = np.empty((n, 1, h, w), np.float32)
+        self._ck(self.lib.fe_u2netp_saliency(self.h, xp, n, h, w, y.ctypes.data_as(_f32p)))
+        return y
+
+    def samp_forward(self, x, want_saliency=False):
+        """x: float32 [n,3,224,224] normalised -> (pattern_weights [n,8], attributes [n,6], score_dist [n,5][, sal])."""
+        x, xp = _f32(x)
+        n = x.shape[0]
+        assert x.shape[1:] == (3, 224, 224)
+        pw = np.empty((n, 8), np.float32)
+        at = np.empty((n, 6), np.float32)
+        sd = np.empty((n, 5), np.float32)
+        sal = np.empty((n, 1, 224, 224), np.float32) if want_saliency else None
+        self._ck(self.lib.fe_samp_forward(self.h, xp, n, pw.ctypes.data_as(_f32p), at.ctypes.data_as(_f32p),
+                                          sd.ctypes.data_as(_f32p),
+                                          sal.ctypes.data_as(_f32p) if want_saliency else None))
+        return (pw, at, sd, sal) if want_saliency else (pw, at, sd)

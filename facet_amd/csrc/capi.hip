@@ -181,6 +181,14 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
     build_resnet(m->backbone, m->dw, ws, "semantic_model.", true, blocks, false);
     if (ws.has("weight_pool.0.splitconv.weight")) build_topiq_head(*m, ws);
     ctx->c.topiq = std::move(m);
+  } else if (model == FE_MODEL_U2NETP) {
+    auto m = std::make_unique<U2NetPModel>();
+    build_u2netp(*m, ws);
+    ctx->c.u2netp = std::move(m);
+  } else if (model == FE_MODEL_SAMP) {
+    auto m = std::make_unique<SampModel>();
+    build_sampnet(*m, ws);
+    ctx->c.samp = std::move(m);
   } else {
     throw Error("fe_weights_commit: model " + std::to_string(model) + " not implemented");
   }
@@ -192,11 +200,15 @@ int fe_model_unload(fe_ctx* ctx, int model) {
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   FE_HIP(hipStreamSynchronize(ctx->c.stream));
   if (model == FE_MODEL_TOPIQ) ctx->c.topiq.reset();
+  if (model == FE_MODEL_U2NETP) ctx->c.u2netp.reset();
+  if (model == FE_MODEL_SAMP) ctx->c.samp.reset();
   FE_API_END(ctx)
 }
 int fe_model_loaded(fe_ctx* ctx, int model) {
   if (!ctx) return 0;
   if (model == FE_MODEL_TOPIQ) return ctx->c.topiq != nullptr;
+  if (model == FE_MODEL_U2NETP) return ctx->c.u2netp != nullptr;
+  if (model == FE_MODEL_SAMP) return ctx->c.samp != nullptr;
   return 0;
 }
 
@@ -368,6 +380,55 @@ int fe_topiq_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_
     FE_HIP(hipMemcpyAsync(scores, d_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, C.stream));
     FE_HIP(hipStreamSynchronize(C.stream));
   }
+  FE_API_END(ctx)
+}
+
+// ---- U2-Net-P + SAMP-Net ---------------------------------------------------------------------------
+// x: host fp32 NCHW [n,3,h,w], already ImageNet-normalised (what SAMPNetScorer.preprocess yields, samp_net.py:904-928)
+int fe_u2netp_saliency(fe_ctx* ctx, const float* x, int n, int h, int w, float* sal_out) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  if (!C.u2netp) { C.err = "u2netp weights not loaded"; return FE_ERR_NOT_LOADED; }
+  FE_CHECK(x && sal_out && n > 0 && h >= 32 && w >= 32, "bad arguments");
+  const size_t per = (size_t)3 * h * w;
+  for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
+    const int nb = std::min(ctx->microbatch, n - i0);
+    C.arena.reset();
+    Tensor xt = upload_nchw(C, x + (size_t)i0 * per, nb, 3, h, w, 4);
+    Tensor sal = C.arena.tensor(nb, h, w, 1);
+    u2netp_forward(C, *C.u2netp, xt, sal);
+    FE_HIP(hipMemcpyAsync(sal_out + (size_t)i0 * h * w, sal.p, (size_t)nb * h * w * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+    FE_HIP(hipStreamSynchronize(C.stream));
+  }
+  FE_API_END(ctx)
+}
+
+// SAMPNetScorer.score_batch's model part (samp_net.py:1005-1010): saliency = U2NETP(x); SAMPNet(x, saliency).
+// Outputs (host): pattern_weights [n,8] (logits), attributes [n,6], score_dist [n,5]; sal_out optional [n,224,224].
+int fe_samp_forward(fe_ctx* ctx, const float* x, int n, float* pattern_weights, float* attributes, float* score_dist,
+                    float* sal_out) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  if (!C.u2netp || !C.samp) { C.err = "samp_net / u2netp weights not loaded"; return FE_ERR_NOT_LOADED; }
+  FE_CHECK(x && n > 0 && pattern_weights && attributes && score_dist, "bad arguments");
+  const int h = 224, w = 224;
+  const size_t per = (size_t)3 * h * w;
+  float* d_out = ctx->out_buf((size_t)n * 19);
+  for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
+    const int nb = std::min(ctx->microbatch, n - i0);
+    C.arena.reset();
+    Tensor xt = upload_nchw(C, x + (size_t)i0 * per, nb, 3, h, w, 4);
+    Tensor sal = C.arena.tensor(nb, h, w, 1);
+    u2netp_forward(C, *C.u2netp, xt, sal);
+    sampnet_forward(C, *C.samp, xt, sal, d_out + (size_t)i0 * 8, d_out + (size_t)n * 8 + (size_t)i0 * 6,
+                    d_out + (size_t)n * 14 + (size_t)i0 * 5);
+    if (sal_out) FE_HIP(hipMemcpyAsync(sal_out + (size_t)i0 * h * w, sal.p, (size_t)nb * h * w * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+    FE_HIP(hipStreamSynchronize(C.stream));
+  }
+  FE_HIP(hipMemcpyAsync(pattern_weights, d_out, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipMemcpyAsync(attributes, d_out + (size_t)n * 8, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipMemcpyAsync(score_dist, d_out + (size_t)n * 14, (size_t)n * 5 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
   FE_API_END(ctx)
 }
 

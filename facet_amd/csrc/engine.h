@@ -113,6 +113,8 @@ struct Ctx {
 
   WeightStore staging[8];
   std::unique_ptr<struct TopiqModel> topiq;
+  std::unique_ptr<struct U2NetPModel> u2netp;
+  std::unique_ptr<struct SampModel> samp;
   ~Ctx();
 };
 
@@ -135,6 +137,30 @@ struct TopiqModel {
   std::vector<float> h_emb, w_emb;           // host copies [128][32] each
   std::map<std::pair<int, int>, float*> pos; // (th,tw) -> device [th*tw][256]
 };
+// ---- U2-Net-P + SAMP-Net (reference models/samp_net.py) ---------------------------------------------
+struct RSUW {
+  ConvW in;
+  std::vector<ConvW> enc;  // rebnconv1..L
+  std::vector<ConvW> dec;  // rebnconv(L-1)d .. rebnconv1d
+  int depth = 0;
+  bool dilated = false;    // RSU4F
+};
+struct U2NetPModel {
+  DeviceWeights dw;
+  RSUW stage[11];          // stage1..6, stage5d..1d
+  ConvW side[6], outconv;
+};
+struct SampModel {
+  DeviceWeights dw;
+  ResNet backbone;         // ResNet-18 trunk
+  ConvW pattern_weight, pattern[8], att_feat, att_pred, com0, com3, com5;
+};
+void build_u2netp(U2NetPModel& m, const WeightStore& ws);
+void build_sampnet(SampModel& m, const WeightStore& ws);
+void u2netp_forward(Ctx& c, const U2NetPModel& m, const Tensor& x_nhwc4, const Tensor& sal);
+void sampnet_forward(Ctx& c, const SampModel& m, const Tensor& x_nhwc4, const Tensor& sal, float* pw, float* attrs,
+                     float* dist);
+
 void build_topiq_head(TopiqModel& m, const WeightStore& ws);
 // feats: the 5 pyramid levels for nb images; scores_dev: device [nb]
 void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<Tensor>& feats, float* scores_dev);

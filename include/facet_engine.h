@@ -103,6 +103,16 @@ int fe_topiq_features(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
 /* raw MOS per image (before the reference's clamp[0,1]*10, pyiqa_scorer.py:166-195) */
 int fe_topiq_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* scores);
 
+/* ---- U2-Net-P + SAMP-Net (reference models/samp_net.py) ------------------------------------------- */
+/* x: fp32 NCHW [n,3,h,w], already Resize(224)+ToTensor+ImageNet-normalised as SAMPNetScorer.preprocess yields
+ * (samp_net.py:904-928). fe_u2netp_saliency = SaliencyDetector.detect (:407-422): sal_out [n,h,w] in (0,1). */
+int fe_u2netp_saliency(fe_ctx* ctx, const float* x, int n, int h, int w, float* sal_out);
+/* = the model part of SAMPNetScorer.score_batch (:1005-1010): saliency = U2NETP(x)[0]; SAMPNet(x, saliency).
+ * x is [n,3,224,224]. Outputs: pattern_weights [n,8] (logits), attributes [n,6], score_dist [n,5];
+ * sal_out may be NULL. Post-processing (softmax/argmax/expectation, :957-989) stays on the host. */
+int fe_samp_forward(fe_ctx* ctx, const float* x, int n, float* pattern_weights, float* attributes, float* score_dist,
+                    float* sal_out);
+
 #ifdef __cplusplus
 }
 #endif
