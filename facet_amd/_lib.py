@@ -63,6 +63,7 @@ SIGNATURES = {
     "fe_op_adaptive_avgpool": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          _f32p]),
     "fe_op_layernorm": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_float, _f32p]),
+    "fe_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int] * 12 + [_f32p]),
     "fe_topiq_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_topiq_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_u2netp_saliency": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
@@ -257,6 +258,12 @@ class Engine:
         y = np.empty_like(x)
         self._ck(self.lib.fe_op_layernorm(self.h, xp, rows, d, gp, bp, eps, y.ctypes.data_as(_f32p)))
         return y
+
+    def bench_conv(self, n, h, w, cin, cout, k, stride=1, pad=0, res=False, act="relu", variant=0, iters=10):
+        ms = C.c_float()
+        self._ck(self.lib.fe_bench_conv(self.h, n, h, w, cin, cout, k, stride, pad, int(res), ACT[act], variant, iters,
+                                        C.byref(ms)))
+        return ms.value
 
     # -- TOPIQ ------------------------------------------------------------------------------
     @staticmethod

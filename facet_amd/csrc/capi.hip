@@ -314,6 +314,48 @@ int fe_op_layernorm(fe_ctx* ctx, const float* x, int rows, int d, const float* g
   FE_API_END(ctx)
 }
 
+// Developer hook: time one conv shape on random data (device-resident), `iters` launches, forced tile variant.
+int fe_bench_conv(fe_ctx* ctx, int n, int h, int w, int cin, int cout, int k, int stride, int pad, int with_res, int act,
+                  int variant, int iters, float* ms_out) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  C.arena.reset();
+  DeviceWeights dw;
+  WeightStore ws;
+  std::vector<float> hw((size_t)cout * cin * k * k);
+  uint32_t st = 12345u;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+  for (auto& v : hw) v = rnd() * 0.1f;
+  const int64_t wshape[4] = {cout, cin, k, k};
+  ws.set("w.weight", hw.data(), wshape, 4);
+  ConvW cw = build_conv(dw, ws, "w", "", false);
+  std::vector<float> sc(cout, 1.01f), sh(cout, 0.1f);
+  cw.scale = dw.upload(sc); cw.shift = dw.upload(sh);
+  Tensor x = C.arena.tensor(n, h, w, cw.CinPad);
+  {
+    std::vector<float> hx((size_t)1 << 20);
+    for (auto& v : hx) v = rnd();
+    for (size_t off = 0; off < x.numel(); off += hx.size())
+      FE_HIP(hipMemcpyAsync(x.p + off, hx.data(), std::min(hx.size(), x.numel() - off) * sizeof(float), hipMemcpyHostToDevice, C.stream));
+    FE_HIP(hipStreamSynchronize(C.stream));
+  }
+  ConvOpts o; o.sh = o.sw = stride; o.ph = o.pw = pad; o.act = act;
+  Tensor y = C.arena.tensor(n, conv_out_dim(h, k, stride, pad, 1), conv_out_dim(w, k, stride, pad, 1), cout);
+  Tensor r;
+  if (with_res) { r = C.arena.tensor(y.n, y.h, y.w, y.c); FE_HIP(hipMemsetAsync(r.p, 0, r.numel() * sizeof(float), C.stream)); o.res = &r; }
+  C.force_variant = variant;
+  conv_forward(C, cw, x, y, o);  // warm
+  FE_HIP(hipEventRecord(ctx->t0, C.stream));
+  for (int i = 0; i < iters; ++i) conv_forward(C, cw, x, y, o);
+  FE_HIP(hipEventRecord(ctx->t1, C.stream));
+  FE_HIP(hipEventSynchronize(ctx->t1));
+  C.force_variant = 0;
+  float ms = 0.f;
+  FE_HIP(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
+  *ms_out = ms / iters;
+  FE_API_END(ctx)
+}
+
 // ---- TOPIQ ------------------------------------------------------------------------------------------
 static const float kImagenetMean[3] = {0.485f, 0.456f, 0.406f};
 static const float kImagenetStd[3] = {0.229f, 0.224f, 0.225f};

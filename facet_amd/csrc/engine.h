@@ -110,6 +110,7 @@ struct Ctx {
   bool profile = false;
   std::vector<OpTiming> timings;
   double flops_accum = 0.0;
+  int force_variant = 0;   // developer hook: forwarded to ConvParams.variant
 
   WeightStore staging[8];
   std::unique_ptr<struct TopiqModel> topiq;

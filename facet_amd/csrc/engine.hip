@@ -145,6 +145,7 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
   p.M = (int)y.pixels();
   FE_CHECK(y.pixels() < (1ull << 31), "conv: M too large");
   p.act = o.act; p.res_after_act = o.res_after_act;
+  p.variant = c.force_variant;
   if (c.profile) {
     hipEvent_t e0, e1;
     FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));

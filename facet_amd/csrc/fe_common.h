@@ -118,6 +118,8 @@ struct ConvParams {
   // batched launches (gridDim.y = batch): b = bo*nb1 + bi; pointer += bo*s2 + bi*s1 (element strides)
   int batch, nb1;
   long long xs1, xs2, ws1, ws2, ys1, ys2, hs1;   // hs1: shift stride per inner index
+  int dbg;                          // timing experiments only (bit0 skip global loads, bit1 skip LDS stores, bit2 skip barrier)
+  int variant;                      // 0 = auto tile choice; >0 forces a tile variant (tools/conv_bench.py)
 };
 
 // Packed conv weight living in HBM.
@@ -139,6 +141,7 @@ struct ConvOpts {
 constexpr int CONV_KALIGN = 32;  // Kp is a multiple of this (covers BK = 16 and 32)
 
 void launch_conv(const ConvParams& p, hipStream_t s);
+void launch_conv_dma(const ConvParams& p, int tile, hipStream_t s);  // LDS-DMA fast path (kernels_conv_dma.hip)
 double conv_flops(const ConvParams& p);
 
 // ---------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 // The k order inside an 8-wide step is permuted (lane half h, element j <-> k = 8s + 4h + j) so each
 // lane fetches its four A (and B) operands of a step with ONE 16-byte LDS read.
 #include "fe_common.h"
+#include <cstdlib>
 
 namespace fe {
 
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, const int
   const int arow = wm * TM * 32 + r, brow = wn * TN * 32 + r;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < nk && !(p.dbg & 1)) load_tile(kt + 1);
     const float* Ab = As + (buf * BM + arow) * S + h * 4;
     const float* Bb = Bs + (buf * BN + brow) * S + h * 4;
 #pragma unroll
@@ -177,8 +178,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, const int
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
-    __syncthreads();
+    if (kt + 1 < nk && !(p.dbg & 2)) store_tile(buf ^ 1);
+    if (!(p.dbg & 4)) __syncthreads();
   }
 
   // ---- epilogue -----------------------------------------------------------------------------------
@@ -275,6 +276,21 @@ static void launch_variant(const ConvParams& p, hipStream_t s) {
   FE_HIP(hipGetLastError());
 }
 
+// Forced tile variants for A/B timing (FAST path only).
+static void launch_forced(const ConvParams& q, hipStream_t s) {
+  FE_CHECK(q.Cin % 16 == 0, "forced variants need Cin %% 16 == 0");
+  switch (q.variant) {
+    case 1: launch_variant<2, 2, 2, 2, 16, true>(q, s); break;   // 128x128
+    case 2: launch_variant<4, 1, 2, 2, 16, true>(q, s); break;   // 256x64
+    case 3: launch_variant<4, 1, 2, 1, 16, true>(q, s); break;   // 256x32
+    case 4: launch_variant<2, 2, 1, 1, 16, true>(q, s); break;   // 64x64
+    case 5: launch_variant<2, 2, 2, 2, 32, true>(q, s); break;   // 128x128 BK32
+    case 6: launch_variant<1, 4, 2, 2, 16, true>(q, s); break;   // 64x256
+    case 7: launch_variant<2, 2, 2, 1, 16, true>(q, s); break;   // 128x64
+    default: FE_CHECK(false, "unknown conv variant %d", q.variant);
+  }
+}
+
 double conv_flops(const ConvParams& p) { return 2.0 * (double)p.M * p.K * p.Cout; }
 
 void launch_conv(const ConvParams& p, hipStream_t s) {
@@ -294,12 +310,32 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
               (!p.gate || p.gate_c1 || (p.ldg % 4 == 0 && al16(p.gate))) && (!p.scale || al16(p.scale)) &&
               (!p.shift || (al16(p.shift) && p.hs1 % 4 == 0)) && (p.batch <= 1 || (p.ys1 % 4 == 0 && p.ys2 % 4 == 0));
   const bool fast = (p.Cin % 16 == 0);
-  // Tile choice: wide-N tiles for Cout >= 128, tall tiles for narrow outputs.
+  static const bool bk32 = getenv("FE_BK32") != nullptr;   // experiment switch (tools/perf_topiq.py)
+  const bool f32 = bk32 && (p.Cin % 32 == 0);
+  // Tile choice: 128x128 for wide outputs, 256x64 / 256x32 for narrow ones; problems too small to give every
+  // CU a 128x128 tile drop to 64x64 tiles (4x the workgroups).
+  if (q.variant > 10 && q.variant < 20) { launch_conv_dma(q, q.variant - 10, s); return; }
+  if (q.variant > 0) { q.dbg = q.variant / 100; q.variant %= 100; launch_forced(q, s); return; }
+  static const bool no_dma = getenv("FE_NO_DMA") != nullptr;
+  if (!no_dma && p.Cin % 16 == 0 && p.KH * p.KW < 64) {
+    const long long wg = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * q.batch;
+    int tile;
+    if (p.Cout > 64) tile = wg < 384 ? 4 : 1;
+    else if (p.Cout > 32) tile = wg < 192 ? 4 : 2;
+    else tile = 3;
+    launch_conv_dma(q, tile, s);
+    return;
+  }
+  const long long wg128 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * q.batch;
   if (p.Cout > 64) {
-    if (fast) launch_variant<2, 2, 2, 2, 16, true>(q, s);
+    if (wg128 < 384 && fast) launch_variant<2, 2, 1, 1, 16, true>(q, s);
+    else if (f32) launch_variant<2, 2, 2, 2, 32, true>(q, s);
+    else if (fast) launch_variant<2, 2, 2, 2, 16, true>(q, s);
     else launch_variant<2, 2, 2, 2, 16, false>(q, s);
   } else if (p.Cout > 32) {
-    if (fast) launch_variant<4, 1, 2, 2, 16, true>(q, s);
+    if (wg128 < 192 && fast) launch_variant<2, 2, 1, 1, 16, true>(q, s);
+    else if (f32) launch_variant<4, 1, 2, 2, 32, true>(q, s);
+    else if (fast) launch_variant<4, 1, 2, 2, 16, true>(q, s);
     else launch_variant<4, 1, 2, 2, 16, false>(q, s);
   } else {
     if (fast) launch_variant<4, 1, 2, 1, 16, true>(q, s);

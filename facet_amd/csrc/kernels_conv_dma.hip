@@ -1,0 +1,301 @@
+// Implicit-GEMM convolution, LDS-DMA main loop (the fast path of the engine: Cin % 16 == 0).
+//
+// Same math, tiling and epilogue as conv_igemm_kernel (kernels_conv.hip), but the K-slabs go HBM/L2 -> LDS with
+// `global_load_lds_dwordx4` (no VGPR staging, no ds_write, ~6 VALU of address work per 1 KiB piece):
+//   * LDS image per slab is lane-linear [row][16 floats] (64-B rows, what the DMA writes: wave base + lane*16);
+//     bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle applied on the SOURCE side
+//     (lane at row r, slot q fetches global chunk q ^ ((r>>2)&3)) and mirrored in the read address.
+//   * im2col zero padding: a lane whose tap falls outside the image (or whose row is past M) fetches from a 16-byte
+//     zero page instead; validity of every tap of a row is a 64-bit mask computed once per workgroup.
+//   * per K-step address work is one 64-bit add of a block-uniform tap offset to a per-row base pointer.
+// Three-slab LDS ring: two slabs are in flight while one is consumed (counted vmcnt + one raw s_barrier per K-step).
+#include "fe_common.h"
+
+namespace fe {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ float apply_act_d(float v, int act) {
+  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  return v;
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4))) void conv_dma_kernel(ConvParams p, const int ntiles) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = 16;
+  constexpr int AI = (BM + 63) / 64, BI = (BN + 63) / 64;   // DMA pieces per wave per slab (16 rows x 64 B each)
+  constexpr int SLAB = (BM + BN) * BK;                      // floats per buffer
+  static_assert(WGM * WGN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  if (p.batch > 1) {
+    const int b = blockIdx.y, bo = b / p.nb1, bi = b - bo * p.nb1;
+    p.x += bo * p.xs2 + bi * p.xs1;
+    p.w += bo * p.ws2 + bi * p.ws1;
+    p.y += bo * p.ys2 + bi * p.ys1;
+    if (p.shift) p.shift += bi * p.hs1;
+  }
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int q8 = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+  const int swz = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+  const int mt = swz / ntiles, nt = swz - mt * ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- DMA source coordinates (per lane, fixed for the whole K loop) -------------------------------------
+  const int rsub = lane >> 2, slot = lane & 3;
+  const int gofs = (slot ^ ((rsub >> 2) & 3)) * 4;   // source chunk (floats) after the swizzle
+  const char* abase[AI];
+  unsigned long long amask[AI];
+  const int HoWo = p.Ho * p.Wo;
+  const int ntaps = p.KH * p.KW;
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    const int row = 16 * (4 * j + wave) + rsub;
+    const int m = m0 + row;
+    const bool valid = (row < BM) && (m < p.M);
+    const int mm = valid ? m : 0;
+    const int nimg = mm / HoWo;
+    const int rem = mm - nimg * HoWo;
+    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+    const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
+    const long long pix = ((long long)nimg * p.H + ih0) * p.W + iw0;
+    abase[j] = reinterpret_cast<const char*>(p.x + pix * p.ldx + gofs);
+    unsigned long long mk = 0;
+    if (valid) {
+      for (int tp = 0; tp < ntaps; ++tp) {
+        const int kh = tp / p.KW, kw = tp - kh * p.KW;
+        const int ih = ih0 + kh * p.dh, iw = iw0 + kw * p.dw;
+        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) mk |= 1ull << tp;
+      }
+    }
+    amask[j] = mk;
+  }
+  const char* bbase[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int row = 16 * (4 * j + wave) + rsub;
+    int n = n0 + row;
+    if (n > p.Cout - 1) n = p.Cout - 1;   // columns past Cout are computed on a valid row and discarded
+    bbase[j] = reinterpret_cast<const char*>(p.w + (size_t)n * p.ldw + gofs);
+  }
+  const char* zpage = reinterpret_cast<const char*>(g_zero_page);
+
+  // block-uniform running tap state
+  int tap = 0, kh = 0, kw = 0, ci = 0;
+  const int nk = p.Kp / BK;
+
+  auto issue = [&](int kt, int buf) {
+    float* Ab = smem + buf * SLAB;
+    float* Bb = Ab + BM * BK;
+    const int tb = ((kh * p.dh * p.W + kw * p.dw) * p.ldx + ci) * 4;   // byte offset of this tap/channel slab
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      if (16 * (4 * j + wave) < BM) {
+        const bool ok = (amask[j] >> tap) & 1ull;
+        const char* src = ok ? abase[j] + tb : zpage;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ab + 256 * (4 * j + wave)), 16, 0, 0);
+      }
+    }
+    const int tbb = kt * (BK * 4);
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+      if (16 * (4 * j + wave) < BN)
+        __builtin_amdgcn_global_load_lds((gptr_t)(bbase[j] + tbb), (lptr_t)(Bb + 256 * (4 * j + wave)), 16, 0, 0);
+    }
+    ci += BK;
+    if (ci >= p.Cin) {
+      ci = 0; ++tap;
+      if (++kw == p.KW) { kw = 0; ++kh; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read offsets (floats): row*16 + ((2s+h) ^ sw)*4, sw = (row>>2)&3 = (r>>2)&3
+  const int sw = (r >> 2) & 3;
+  const int fo0 = ((h ^ sw) << 2), fo1 = fo0 ^ 8;
+  const int aoff = (wm * TM * 32 + r) * BK, boff = BM * BK + (wn * TN * 32 + r) * BK;
+
+  // 3-slab ring: slabs t+1 and t+2 are in flight while slab t is consumed. A wave waits only for its OWN pieces
+  // of slab t (counted vmcnt leaves the newer slab's pieces outstanding), then the raw barrier publishes the slab
+  // and retires everybody's reads of the buffer that slab t+2 is about to overwrite.
+  constexpr int NPW_A = BM / 64;                       // pieces every wave issues per slab (BM % 64 == 0)
+  static_assert(BM % 64 == 0, "A pieces must be uniform over waves");
+  const int npw = NPW_A + ((16 * wave < BN) ? 1 : 0) + ((BN > 64 && 16 * (4 + wave) < BN) ? 1 : 0) +
+                  ((BN > 128 && 16 * (8 + wave) < BN) ? 1 : 0) + ((BN > 192 && 16 * (12 + wave) < BN) ? 1 : 0);
+  const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      // leave the newest slab (npw pieces of this wave) in flight
+      if (npw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (npw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (npw == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (npw == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (npw == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (npw == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+    // Fragment reads are inline asm on purpose: hipcc orders every C++ LDS read behind ALL outstanding LDS-DMA
+    // (s_waitcnt vmcnt(0)), which would drain the ring each step. The counted vmcnt + barrier above already
+    // guarantee slab kt has landed; the reads are retired by the explicit lgkmcnt(0) below.
+    const unsigned sb = lds_base + (unsigned)((kt % 3) * SLAB * 4);
+    v4f a0[TM], a1[TM], b0[TN], b1[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(a0[i]) : "v"(sb + (unsigned)((aoff + i * 32 * BK + fo0) * 4)));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(a1[i]) : "v"(sb + (unsigned)((aoff + i * 32 * BK + fo1) * 4)));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(b0[j]) : "v"(sb + (unsigned)((boff + j * 32 * BK + fo0) * 4)));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(b1[j]) : "v"(sb + (unsigned)((boff + j * 32 * BK + fo1) * 4)));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].x, b0[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].y, b0[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].z, b0[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].w, b0[j].w, acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].x, b1[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].y, b1[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].z, b1[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].w, b1[j].w, acc[i][j], 0, 0, 0);
+      }
+  }
+  __syncthreads();   // all fragment reads retired before the epilogue reuses the slabs as staging
+
+  // ---- epilogue (same as conv_igemm_kernel): transpose through a wave-private LDS region ------------------
+  if (p.vec_epi) {
+    constexpr int WC = TN * 32, ES = WC + 4, LPR = WC / 4, RPI = 64 / LPR, NIT = 32 / RPI;
+    float* E = smem + wave * 32 * ES;
+    const int lr = lane / LPR, lc = (lane % LPR) * 4;
+    const int colb = n0 + wn * WC + lc;
+    const bool cok = colb < p.Cout;
+    const int colc = cok ? colb : 0;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + colc);
+    if (p.shift) sf = *reinterpret_cast<const float4*>(p.shift + colc);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
+      const int mrow0 = m0 + wm * TM * 32 + i * 32 + lr;
+      float4 rv[NIT], gv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = mrow0 + it * RPI;
+        const int mc = m < p.M ? m : p.M - 1;
+        if (p.res) rv[it] = *reinterpret_cast<const float4*>(p.res + (size_t)mc * p.ldr + colc);
+        if (p.gate) {
+          if (p.gate_c1) { const float g = p.gate[(size_t)mc * p.ldg]; gv[it] = make_float4(g, g, g, g); }
+          else gv[it] = *reinterpret_cast<const float4*>(p.gate + (size_t)mc * p.ldg + colc);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = mrow0 + it * RPI;
+        float4 v = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc]);
+        v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+        if (p.res && !p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+        v.x = apply_act_d(v.x, p.act); v.y = apply_act_d(v.y, p.act); v.z = apply_act_d(v.z, p.act); v.w = apply_act_d(v.w, p.act);
+        if (p.res && p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+        if (p.gate) { v.x *= gv[it].x; v.y *= gv[it].y; v.z *= gv[it].z; v.w *= gv[it].w; }
+        if (cok && m < p.M) *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + colb) = v;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * TN * 32 + j * 32 + r;
+    const bool cok = col < p.Cout;
+    const float sc = (cok && p.scale) ? p.scale[col] : 1.f;
+    const float sf = (cok && p.shift) ? p.shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = m0 + row;
+        if (cok && m < p.M) {
+          float v = acc[i][j][e] * sc + sf;
+          if (p.res && !p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
+          v = apply_act_d(v, p.act);
+          if (p.res && p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
+          if (p.gate) v *= p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
+          p.y[(size_t)m * p.ldy + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int WGM, int WGN, int TM, int TN>
+static void launch_dma_variant(const ConvParams& p, hipStream_t s) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
+  constexpr size_t main_lds = (size_t)3 * (BM + BN) * 16 * sizeof(float);
+  constexpr size_t epi_lds = (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
+  constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
+  auto kern = conv_dma_kernel<WGM, WGN, TM, TN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, ntiles);
+  FE_HIP(hipGetLastError());
+}
+
+// tile: 1 = 128x128, 2 = 256x64, 3 = 256x32, 4 = 64x64, 7 = 128x64
+void launch_conv_dma(const ConvParams& p, int tile, hipStream_t s) {
+  FE_CHECK(p.Cin % 16 == 0 && p.KH * p.KW < 64, "conv_dma: needs Cin %% 16 == 0 and < 64 taps");
+  switch (tile) {
+    case 1: launch_dma_variant<2, 2, 2, 2>(p, s); break;
+    case 2: launch_dma_variant<4, 1, 2, 2>(p, s); break;
+    case 3: launch_dma_variant<4, 1, 2, 1>(p, s); break;
+    case 4: launch_dma_variant<2, 2, 1, 1>(p, s); break;
+    case 7: launch_dma_variant<2, 2, 2, 1>(p, s); break;
+    case 8: launch_dma_variant<2, 2, 4, 2>(p, s); break;   // 256x128
+    case 9: launch_dma_variant<2, 2, 2, 4>(p, s); break;   // 128x256
+    default: FE_CHECK(false, "conv_dma: unknown tile %d", tile);
+  }
+}
+
+}  // namespace fe
