@@ -66,6 +66,7 @@ SIGNATURES = {
     "fe_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int] * 12 + [_f32p]),
     "fe_topiq_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_topiq_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
+    "fe_clip_encode_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
     "fe_u2netp_saliency": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_samp_forward": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p]),
 }
@@ -313,3 +314,27 @@ class Engine:
                                           sd.ctypes.data_as(_f32p),
                                           sal.ctypes.data_as(_f32p) if want_saliency else None))
         return (pw, at, sd, sal) if want_saliency else (pw, at, sd)
+
+    # -- CLIP -------------------------------------------------------------------------------
+    def clip_encode_image(self, x, normalized=False, aesthetic=False, out_dim=768):
+        """x: float32 [n,3,224,224] (host array) or (device_ptr, n) tuple. Returns features [n,768]
+        (+ normalised embedding, + raw aesthetic score) like Facet.get_aesthetic_and_quality_batch needs."""
+        if isinstance(x, tuple):
+            p, n = x
+            dev, keep = 1, None
+        else:
+            keep = np.ascontiguousarray(x, dtype=np.float32)
+            n, dev = keep.shape[0], 0
+            p = keep.ctypes.data_as(C.c_void_p)
+        feat = np.empty((n, out_dim), np.float32)
+        emb = np.empty((n, out_dim), np.float32) if normalized else None
+        aes = np.empty((n,), np.float32) if aesthetic else None
+        self._ck(self.lib.fe_clip_encode_image(self.h, p, n, dev, feat.ctypes.data_as(_f32p),
+                                               emb.ctypes.data_as(_f32p) if normalized else None,
+                                               aes.ctypes.data_as(_f32p) if aesthetic else None))
+        out = [feat]
+        if normalized:
+            out.append(emb)
+        if aesthetic:
+            out.append(aes)
+        return out[0] if len(out) == 1 else tuple(out)

@@ -1,6 +1,7 @@
 // C ABI of libfacet_engine.so (declared in include/facet_engine.h).
 #include "../../include/facet_engine.h"
 #include "engine.h"
+#include <cmath>
 
 using namespace fe;
 
@@ -185,6 +186,14 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
     auto m = std::make_unique<U2NetPModel>();
     build_u2netp(*m, ws);
     ctx->c.u2netp = std::move(m);
+  } else if (model == FE_MODEL_CLIP) {
+    auto m = std::make_unique<ClipModel>();
+    build_clip(*m, ws);
+    ctx->c.clip = std::move(m);
+  } else if (model == FE_MODEL_AESTHETIC) {
+    auto m = std::make_unique<AestheticModel>();
+    build_aesthetic(*m, ws);
+    ctx->c.aesthetic = std::move(m);
   } else if (model == FE_MODEL_SAMP) {
     auto m = std::make_unique<SampModel>();
     build_sampnet(*m, ws);
@@ -202,6 +211,8 @@ int fe_model_unload(fe_ctx* ctx, int model) {
   if (model == FE_MODEL_TOPIQ) ctx->c.topiq.reset();
   if (model == FE_MODEL_U2NETP) ctx->c.u2netp.reset();
   if (model == FE_MODEL_SAMP) ctx->c.samp.reset();
+  if (model == FE_MODEL_CLIP) ctx->c.clip.reset();
+  if (model == FE_MODEL_AESTHETIC) ctx->c.aesthetic.reset();
   FE_API_END(ctx)
 }
 int fe_model_loaded(fe_ctx* ctx, int model) {
@@ -209,6 +220,8 @@ int fe_model_loaded(fe_ctx* ctx, int model) {
   if (model == FE_MODEL_TOPIQ) return ctx->c.topiq != nullptr;
   if (model == FE_MODEL_U2NETP) return ctx->c.u2netp != nullptr;
   if (model == FE_MODEL_SAMP) return ctx->c.samp != nullptr;
+  if (model == FE_MODEL_CLIP) return ctx->c.clip != nullptr;
+  if (model == FE_MODEL_AESTHETIC) return ctx->c.aesthetic != nullptr;
   return 0;
 }
 
@@ -470,6 +483,43 @@ int fe_samp_forward(fe_ctx* ctx, const float* x, int n, float* pattern_weights, 
   FE_HIP(hipMemcpyAsync(pattern_weights, d_out, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipMemcpyAsync(attributes, d_out + (size_t)n * 8, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipMemcpyAsync(score_dist, d_out + (size_t)n * 14, (size_t)n * 5 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+// ---- CLIP ------------------------------------------------------------------------------------------
+// x: fp32 NCHW [n,3,224,224] as open_clip's eval transform yields (host, or device when on_device).
+// features [n,768] un-normalised (= model.encode_image); emb_norm (nullable) = F.normalize(features);
+// aesthetic_raw (nullable, needs FE_MODEL_AESTHETIC) = aesthetic_head(features) before the (x+1)*5 clamp.
+int fe_clip_encode_image(fe_ctx* ctx, const float* x, int n, int on_device, float* features, float* emb_norm,
+                         float* aesthetic_raw) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  if (!C.clip) { C.err = "clip weights not loaded"; return FE_ERR_NOT_LOADED; }
+  if (aesthetic_raw && !C.aesthetic) { C.err = "aesthetic head weights not loaded"; return FE_ERR_NOT_LOADED; }
+  FE_CHECK(x && n > 0 && (features || emb_norm || aesthetic_raw), "bad arguments");
+  const int hw = C.clip->patch_size * (int)std::lround(std::sqrt((double)(C.clip->tokens - 1)));
+  const int od = C.clip->out_dim;
+  const size_t per = (size_t)3 * hw * hw;
+  float* d_out = ctx->out_buf((size_t)n * (2 * od + 1));
+  float* d_feat = d_out; float* d_norm = d_out + (size_t)n * od; float* d_aes = d_out + (size_t)n * 2 * od;
+  for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
+    const int nb = std::min(ctx->microbatch, n - i0);
+    C.arena.reset();
+    Tensor xt;
+    if (on_device) {
+      xt = C.arena.tensor(nb, hw, hw, 4);
+      launch_nchw_to_nhwc(x + (size_t)i0 * per, xt.p, nb, 3, hw, hw, 4, C.stream);
+    } else {
+      xt = upload_nchw(C, x + (size_t)i0 * per, nb, 3, hw, hw, 4);
+    }
+    clip_forward(C, *C.clip, xt, d_feat + (size_t)i0 * od);
+    if (emb_norm) l2_normalize(C, d_feat + (size_t)i0 * od, d_norm + (size_t)i0 * od, nb, od);
+    if (aesthetic_raw) aesthetic_forward(C, *C.aesthetic, d_feat + (size_t)i0 * od, nb, d_aes + i0);
+  }
+  if (features) FE_HIP(hipMemcpyAsync(features, d_feat, (size_t)n * od * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  if (emb_norm) FE_HIP(hipMemcpyAsync(emb_norm, d_norm, (size_t)n * od * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  if (aesthetic_raw) FE_HIP(hipMemcpyAsync(aesthetic_raw, d_aes, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipStreamSynchronize(C.stream));
   FE_API_END(ctx)
 }

@@ -116,6 +116,8 @@ struct Ctx {
   std::unique_ptr<struct TopiqModel> topiq;
   std::unique_ptr<struct U2NetPModel> u2netp;
   std::unique_ptr<struct SampModel> samp;
+  std::unique_ptr<struct ClipModel> clip;
+  std::unique_ptr<struct AestheticModel> aesthetic;
   ~Ctx();
 };
 
@@ -161,6 +163,23 @@ void build_sampnet(SampModel& m, const WeightStore& ws);
 void u2netp_forward(Ctx& c, const U2NetPModel& m, const Tensor& x_nhwc4, const Tensor& sal);
 void sampnet_forward(Ctx& c, const SampModel& m, const Tensor& x_nhwc4, const Tensor& sal, float* pw, float* attrs,
                      float* dist);
+
+// ---- CLIP ViT image tower + aesthetic MLP -------------------------------------------------------------
+struct ClipBlockW { LayerNormW ln1, ln2; MHAW attn; ConvW fc, proj; };
+struct ClipModel {
+  DeviceWeights dw;
+  ConvW patch, proj;
+  float* pos = nullptr; float* cls = nullptr;
+  LayerNormW ln_pre, ln_post;
+  std::vector<ClipBlockW> blocks;
+  int width = 0, heads = 0, tokens = 0, patch_size = 0, out_dim = 0;
+};
+struct AestheticModel { DeviceWeights dw; ConvW l0, l2; };
+void build_clip(ClipModel& m, const WeightStore& ws);
+void build_aesthetic(AestheticModel& m, const WeightStore& ws);
+void clip_forward(Ctx& c, const ClipModel& m, const Tensor& x_nhwc4, float* feat);
+void aesthetic_forward(Ctx& c, const AestheticModel& m, const float* feat, int B, float* raw);
+void l2_normalize(Ctx& c, const float* x, float* y, int rows, int d);
 
 void build_topiq_head(TopiqModel& m, const WeightStore& ws);
 // feats: the 5 pyramid levels for nb images; scores_dev: device [nb]

@@ -117,6 +117,15 @@ int fe_u2netp_saliency(fe_ctx* ctx, const float* x, int n, int h, int w, float* 
 int fe_samp_forward(fe_ctx* ctx, const float* x, int n, float* pattern_weights, float* attributes, float* score_dist,
                     float* sal_out);
 
+/* ---- CLIP ViT-L/14 image tower + aesthetic MLP (reference processing/scorer.py:640-673) ------------- */
+/* x: fp32 NCHW [n,3,224,224] as open_clip's eval transform yields. Any of the three outputs may be NULL:
+ *   features      [n,768] = model.encode_image(x)                          (scorer.py:662)
+ *   emb_norm      [n,768] = F.normalize(features, dim=-1)                  (:663; stored as 3072-byte blobs, :670)
+ *   aesthetic_raw [n]     = aesthetic_head(features) (Linear-ReLU-Linear)  (:664; the (x+1)*5 clamp [0,10] stays on host, :669)
+ */
+int fe_clip_encode_image(fe_ctx* ctx, const float* x, int n, int on_device, float* features, float* emb_norm,
+                         float* aesthetic_raw);
+
 #ifdef __cplusplus
 }
 #endif
