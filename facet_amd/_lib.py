@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libfacet_engine.so")
 
 FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_SAMP, FE_MODEL_U2NETP, FE_MODEL_AESTHETIC = range(5)
 FE_MODEL_SCRFD, FE_MODEL_ARCFACE = 5, 6
+FE_RECORD_FLOATS = 789
+FILTERS = {"lanczos": 1, "bilinear": 2, "bicubic": 3}
 ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3}
 
 
@@ -67,6 +69,13 @@ SIGNATURES = {
     "fe_topiq_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_topiq_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_clip_encode_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
+    "fe_resize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p]),
+    "fe_clip_encode_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
+    "fe_samp_score_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
+                                       _f32p, _f32p]),
+    "fe_ensemble_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
+                                    C.POINTER(C.c_int)]),
     "fe_u2netp_saliency": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_samp_forward": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p]),
 }
@@ -338,3 +347,40 @@ class Engine:
         if aesthetic:
             out.append(aes)
         return out[0] if len(out) == 1 else tuple(out)
+
+    # -- preprocessing + image-level entry points ------------------------------------------
+    def resize_u8(self, imgs, oh, ow, filter="bilinear"):
+        """PIL-exact resize of a uint8 [n,h,w,3] batch -> [n,oh,ow,3]."""
+        a = np.ascontiguousarray(imgs, dtype=np.uint8)
+        n, h, w, _ = a.shape
+        out = np.empty((n, oh, ow, 3), np.uint8)
+        self._ck(self.lib.fe_resize_u8(self.h, a.ctypes.data_as(C.c_void_p), n, h, w, oh, ow, FILTERS[filter], 0,
+                                       out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def clip_encode_images(self, images, normalized=True, aesthetic=True):
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        feat = np.empty((n, 768), np.float32)
+        emb = np.empty((n, 768), np.float32) if normalized else None
+        aes = np.empty((n,), np.float32) if aesthetic else None
+        self._ck(self.lib.fe_clip_encode_images(self.h, p, n, h, w, dev, feat.ctypes.data_as(_f32p),
+                                                emb.ctypes.data_as(_f32p) if normalized else None,
+                                                aes.ctypes.data_as(_f32p) if aesthetic else None))
+        return feat, emb, aes
+
+    def samp_score_images(self, images, bgr=False):
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        pw = np.empty((n, 8), np.float32)
+        at = np.empty((n, 6), np.float32)
+        sd = np.empty((n, 5), np.float32)
+        self._ck(self.lib.fe_samp_score_images(self.h, p, n, h, w, int(bgr), dev, pw.ctypes.data_as(_f32p),
+                                               at.ctypes.data_as(_f32p), sd.ctypes.data_as(_f32p)))
+        return pw, at, sd
+
+    def ensemble_score(self, images):
+        """-> (records float32 [n, 789], models_run bitmask). Layout: include/facet_engine.h fe_ensemble_score."""
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        rec = np.empty((n, FE_RECORD_FLOATS), np.float32)
+        mask = C.c_int(0)
+        self._ck(self.lib.fe_ensemble_score(self.h, p, n, h, w, dev, rec.ctypes.data_as(_f32p), C.byref(mask)))
+        return rec, mask.value

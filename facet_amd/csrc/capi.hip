@@ -524,4 +524,177 @@ int fe_clip_encode_image(fe_ctx* ctx, const float* x, int n, int on_device, floa
   FE_API_END(ctx)
 }
 
+// ---- PIL-exact resize + image-level entry points ---------------------------------------------------------
+static const float kClipMean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+static const float kClipStd[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+
+static int py_round_half_even(double v) {
+  const double f = std::floor(v);
+  const double d = v - f;
+  if (d > 0.5) return (int)f + 1;
+  if (d < 0.5) return (int)f;
+  return ((long long)f % 2 == 0) ? (int)f : (int)f + 1;
+}
+
+// device u8 batch -> device u8 batch resized like PIL (+ crop)
+int fe_resize_u8(fe_ctx* ctx, const uint8_t* src, int n, int h, int w, int oh, int ow, int filter, int on_device,
+                 uint8_t* dst) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(src && dst && n > 0, "bad arguments");
+  C.arena.reset();
+  const size_t in_b = (size_t)n * h * w * 3, out_b = (size_t)n * oh * ow * 3;
+  const uint8_t* d_in = src;
+  uint8_t* d_out = dst;
+  if (!on_device) {
+    uint8_t* t = (uint8_t*)C.arena.alloc(in_b);
+    FE_HIP(hipMemcpyAsync(t, src, in_b, hipMemcpyHostToDevice, C.stream));
+    d_in = t;
+    d_out = (uint8_t*)C.arena.alloc(out_b);
+  }
+  resize_u8(C, d_in, n, h, w, oh, ow, filter, 0, oh, 0, ow, d_out);
+  if (!on_device) FE_HIP(hipMemcpyAsync(dst, d_out, out_b, hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+// uint8 images -> the model's normalised NHWC4 input, preprocessing exactly like the reference's PIL/torchvision path
+static Tensor preprocess_square224(Ctx& C, const uint8_t* d_rgb, int nb, int h, int w, int filter, bool shorter_side_crop,
+                                   const float mean[3], const float stdv[3], int bgr) {
+  int oh = 224, ow = 224, y0 = 0, x0 = 0;
+  if (shorter_side_crop) {  // torchvision Resize(224) + CenterCrop(224)
+    if (w <= h) { ow = 224; oh = (int)(224.0 * h / w); } else { oh = 224; ow = (int)(224.0 * w / h); }
+    y0 = py_round_half_even((oh - 224) / 2.0);
+    x0 = py_round_half_even((ow - 224) / 2.0);
+  }
+  uint8_t* small = (uint8_t*)C.arena.alloc((size_t)nb * 224 * 224 * 3);
+  resize_u8(C, d_rgb, nb, h, w, oh, ow, filter, y0, 224, x0, 224, small);
+  Tensor x = C.arena.tensor(nb, 224, 224, 4);
+  launch_u8_to_nhwc4_norm(small, x.p, (size_t)nb * 224 * 224, mean, stdv, bgr, C.stream);
+  return x;
+}
+
+static const uint8_t* stage_images(Ctx& C, const uint8_t* imgs, size_t bytes, int on_device) {
+  if (on_device) return imgs;
+  uint8_t* d = (uint8_t*)C.arena.alloc(bytes);
+  FE_HIP(hipMemcpyAsync(d, imgs, bytes, hipMemcpyHostToDevice, C.stream));
+  return d;
+}
+
+// CLIP from raw images: open_clip eval transform (bicubic shorter-side 224, center crop, CLIP mean/std) + tower.
+int fe_clip_encode_images(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* features,
+                          float* emb_norm, float* aesthetic_raw) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  if (!C.clip) { C.err = "clip weights not loaded"; return FE_ERR_NOT_LOADED; }
+  if (aesthetic_raw && !C.aesthetic) { C.err = "aesthetic head weights not loaded"; return FE_ERR_NOT_LOADED; }
+  FE_CHECK(rgb && n > 0 && h > 0 && w > 0, "bad arguments");
+  const int od = C.clip->out_dim;
+  const size_t per = (size_t)h * w * 3;
+  float* d_out = ctx->out_buf((size_t)n * (2 * od + 1));
+  float* d_feat = d_out; float* d_norm = d_out + (size_t)n * od; float* d_aes = d_out + (size_t)n * 2 * od;
+  for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
+    const int nb = std::min(ctx->microbatch, n - i0);
+    C.arena.reset();
+    const uint8_t* d_in = stage_images(C, rgb + (size_t)i0 * per, nb * per, on_device);
+    Tensor xt = preprocess_square224(C, d_in, nb, h, w, FE_FILTER_BICUBIC, true, kClipMean, kClipStd, 0);
+    clip_forward(C, *C.clip, xt, d_feat + (size_t)i0 * od);
+    if (emb_norm) l2_normalize(C, d_feat + (size_t)i0 * od, d_norm + (size_t)i0 * od, nb, od);
+    if (aesthetic_raw) aesthetic_forward(C, *C.aesthetic, d_feat + (size_t)i0 * od, nb, d_aes + i0);
+  }
+  if (features) FE_HIP(hipMemcpyAsync(features, d_feat, (size_t)n * od * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  if (emb_norm) FE_HIP(hipMemcpyAsync(emb_norm, d_norm, (size_t)n * od * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  if (aesthetic_raw) FE_HIP(hipMemcpyAsync(aesthetic_raw, d_aes, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+// SAMPNetScorer.score_batch from raw images (samp_net.py:904-928, 991-1010): BGR->RGB if bgr, PIL bilinear
+// Resize((224,224)), ToTensor, ImageNet Normalize, U2NETP saliency, SAMPNet.
+int fe_samp_score_images(fe_ctx* ctx, const uint8_t* img, int n, int h, int w, int bgr, int on_device,
+                         float* pattern_weights, float* attributes, float* score_dist) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  if (!C.u2netp || !C.samp) { C.err = "samp_net / u2netp weights not loaded"; return FE_ERR_NOT_LOADED; }
+  FE_CHECK(img && n > 0 && pattern_weights && attributes && score_dist, "bad arguments");
+  const size_t per = (size_t)h * w * 3;
+  float* d_out = ctx->out_buf((size_t)n * 19);
+  for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
+    const int nb = std::min(ctx->microbatch, n - i0);
+    C.arena.reset();
+    const uint8_t* d_in = stage_images(C, img + (size_t)i0 * per, nb * per, on_device);
+    Tensor xt = preprocess_square224(C, d_in, nb, h, w, FE_FILTER_BILINEAR, false, kImagenetMean, kImagenetStd, bgr);
+    Tensor sal = C.arena.tensor(nb, 224, 224, 1);
+    u2netp_forward(C, *C.u2netp, xt, sal);
+    sampnet_forward(C, *C.samp, xt, sal, d_out + (size_t)i0 * 8, d_out + (size_t)n * 8 + (size_t)i0 * 6,
+                    d_out + (size_t)n * 14 + (size_t)i0 * 5);
+  }
+  FE_HIP(hipMemcpyAsync(pattern_weights, d_out, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipMemcpyAsync(attributes, d_out + (size_t)n * 8, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipMemcpyAsync(score_dist, d_out + (size_t)n * 14, (size_t)n * 5 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+// One call per batch for the whole ensemble (what processing/batch_processor.py:169-360 sequences per image):
+// record[i] = [topiq_raw, aesthetic_raw, pattern_weights(8), attributes(6), score_dist(5), clip_emb_norm(768)] = 789 floats.
+// Models that are not loaded leave their fields at 0 (mask bit i of *models_run: 1 topiq, 2 clip, 4 samp).
+int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* records, int* models_run) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(rgb && records && n > 0 && h >= 32 && w >= 32, "bad arguments");
+  const int R = FE_RECORD_FLOATS;
+  const size_t per = (size_t)h * w * 3;
+  // SoA planes on the device (every plane 16-B aligned), interleaved into records on the host copy
+  const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
+  const size_t o_aes = n4, o_pw = 2 * n4, o_at = o_pw + 8 * n4, o_sd = o_at + 6 * n4, o_emb = o_sd + 5 * n4,
+               o_feat = o_emb + 768 * n4, total = o_feat + 768 * n4;
+  float* d_rec = ctx->out_buf(total);
+  FE_HIP(hipMemsetAsync(d_rec, 0, total * sizeof(float), C.stream));
+  const bool do_topiq = C.topiq && C.topiq->has_head, do_clip = (bool)C.clip, do_samp = C.samp && C.u2netp;
+  float* p_topiq = d_rec;  float* p_aes = d_rec + o_aes;  float* p_pw = d_rec + o_pw;  float* p_at = d_rec + o_at;
+  float* p_sd = d_rec + o_sd;  float* p_emb = d_rec + o_emb;  float* d_feat = d_rec + o_feat;
+  for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
+    const int nb = std::min(ctx->microbatch, n - i0);
+    C.arena.reset();
+    const uint8_t* d_in = stage_images(C, rgb + (size_t)i0 * per, nb * per, on_device);
+    if (do_topiq) {
+      const size_t mark = C.arena.mark();
+      std::vector<Tensor> feats;
+      topiq_backbone_chunk(ctx, d_in, nb, h, w, feats);
+      topiq_head_forward(C, *C.topiq, feats, p_topiq + i0);
+      C.arena.rewind(mark);
+    }
+    if (do_clip) {
+      const size_t mark = C.arena.mark();
+      Tensor xt = preprocess_square224(C, d_in, nb, h, w, FE_FILTER_BICUBIC, true, kClipMean, kClipStd, 0);
+      clip_forward(C, *C.clip, xt, d_feat + (size_t)i0 * 768);
+      l2_normalize(C, d_feat + (size_t)i0 * 768, p_emb + (size_t)i0 * 768, nb, 768);
+      if (C.aesthetic) aesthetic_forward(C, *C.aesthetic, d_feat + (size_t)i0 * 768, nb, p_aes + i0);
+      C.arena.rewind(mark);
+    }
+    if (do_samp) {
+      const size_t mark = C.arena.mark();
+      Tensor xt = preprocess_square224(C, d_in, nb, h, w, FE_FILTER_BILINEAR, false, kImagenetMean, kImagenetStd, 0);
+      Tensor sal = C.arena.tensor(nb, 224, 224, 1);
+      u2netp_forward(C, *C.u2netp, xt, sal);
+      sampnet_forward(C, *C.samp, xt, sal, p_pw + (size_t)i0 * 8, p_at + (size_t)i0 * 6, p_sd + (size_t)i0 * 5);
+      C.arena.rewind(mark);
+    }
+  }
+  std::vector<float> host(o_feat);
+  FE_HIP(hipMemcpyAsync(host.data(), d_rec, host.size() * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  for (int i = 0; i < n; ++i) {
+    float* r = records + (size_t)i * R;
+    r[0] = host[i]; r[1] = host[o_aes + i];
+    memcpy(r + 2, &host[o_pw + (size_t)i * 8], 8 * sizeof(float));
+    memcpy(r + 10, &host[o_at + (size_t)i * 6], 6 * sizeof(float));
+    memcpy(r + 16, &host[o_sd + (size_t)i * 5], 5 * sizeof(float));
+    memcpy(r + 21, &host[o_emb + (size_t)i * 768], 768 * sizeof(float));
+  }
+  if (models_run) *models_run = (do_topiq ? 1 : 0) | (do_clip ? 2 : 0) | (do_samp ? 4 : 0);
+  FE_API_END(ctx)
+}
+
 }  // extern "C"

@@ -2,6 +2,7 @@
 #pragma once
 #include "fe_common.h"
 #include <memory>
+#include <tuple>
 
 namespace fe {
 
@@ -98,6 +99,14 @@ void build_resnet(ResNet& r, DeviceWeights& dw, const WeightStore& ws, const std
 // feats (optional) receives [stem-relu, layer1..layer4]; returns layer4 output.
 Tensor resnet_forward(Ctx& c, const ResNet& r, const Tensor& x_nhwc4, std::vector<Tensor>* feats);
 
+// ---- PIL-exact uint8 resampling (kernels_resize.hip) --------------------------------------------------
+enum ResizeFilter : int { FE_FILTER_LANCZOS = 1, FE_FILTER_BILINEAR = 2, FE_FILTER_BICUBIC = 3 };  // PIL's enum values
+struct ResizeCoeffs { std::vector<int> kk, bounds; int ksize = 0, out = 0; };
+struct ResizeCoeffsDev { int* kk = nullptr; int* bounds = nullptr; int ksize = 0; };
+void build_resize_coeffs(int in_size, int out_size, int filter, ResizeCoeffs& rc);
+void resize_u8(Ctx& c, const uint8_t* d_src, int n, int h, int w, int oh, int ow, int filter, int y0, int ch, int x0,
+               int cw, uint8_t* d_dst);
+
 struct OpTiming { std::string name; double flops; double bytes; float ms; };
 
 struct Ctx {
@@ -112,6 +121,7 @@ struct Ctx {
   double flops_accum = 0.0;
   int force_variant = 0;   // developer hook: forwarded to ConvParams.variant
 
+  std::map<std::tuple<int, int, int>, ResizeCoeffsDev> resize_cache;  // (in, out, filter) -> device tables
   WeightStore staging[8];
   std::unique_ptr<struct TopiqModel> topiq;
   std::unique_ptr<struct U2NetPModel> u2netp;

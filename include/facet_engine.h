@@ -126,6 +126,32 @@ int fe_samp_forward(fe_ctx* ctx, const float* x, int n, float* pattern_weights, 
 int fe_clip_encode_image(fe_ctx* ctx, const float* x, int n, int on_device, float* features, float* emb_norm,
                          float* aesthetic_raw);
 
+/* ---- preprocessing: PIL-exact uint8 resampling (bit-for-bit PIL.Image.resize, RGB 8-bit) ---------------- */
+enum fe_filter { FE_LANCZOS = 1, FE_BILINEAR = 2, FE_BICUBIC = 3 }; /* PIL.Image.Resampling values */
+/* src [n,h,w,3] uint8 -> dst [n,oh,ow,3] uint8; replaces PIL `image.resize((ow,oh), filter)`
+ * (models/pyiqa_scorer.py:153 LANCZOS; torchvision Resize inside models/samp_net.py:823-830; open_clip transform). */
+int fe_resize_u8(fe_ctx* ctx, const uint8_t* src, int n, int h, int w, int oh, int ow, int filter, int on_device,
+                 uint8_t* dst);
+
+/* ---- image-level entry points (uint8 HWC images in, per-image results out) ------------------------------ */
+/* CLIP from raw RGB images: open_clip eval transform on the GPU (PIL-bicubic shorter side -> 224, center crop 224,
+ * /255, CLIP mean/std) + fe_clip_encode_image. Replaces batch_processor.py:95 `scorer.preprocess(pil)` +
+ * scorer.py:640-673. */
+int fe_clip_encode_images(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* features,
+                          float* emb_norm, float* aesthetic_raw);
+/* SAMPNetScorer.score_batch from raw images (samp_net.py:904-928,991-1010): optional BGR->RGB, PIL-bilinear
+ * Resize((224,224)), ToTensor, ImageNet Normalize, U2NETP saliency, SAMPNet. Outputs as fe_samp_forward. */
+int fe_samp_score_images(fe_ctx* ctx, const uint8_t* img, int n, int h, int w, int bgr, int on_device,
+                         float* pattern_weights, float* attributes, float* score_dist);
+/* The whole ensemble on one resident batch — what processing/batch_processor.py:169-360 sequences per image.
+ * records [n][FE_RECORD_FLOATS]: [0] topiq raw MOS, [1] aesthetic raw, [2..9] SAMP pattern logits, [10..15] SAMP
+ * attributes, [16..20] SAMP score distribution, [21..788] L2-normalised CLIP embedding. Fields of models that are
+ * not loaded stay 0; *models_run (nullable) = bitmask 1 topiq | 2 clip | 4 samp. This is also the fixed-size
+ * per-image record that ranks all-gather in multi-GPU runs. */
+#define FE_RECORD_FLOATS 789
+int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* records,
+                      int* models_run);
+
 #ifdef __cplusplus
 }
 #endif
