@@ -1,0 +1,100 @@
+"""Drop-in CLIP handle for the reference's `{'model': m, 'preprocess': fn}` (models/model_manager.py:145-148) and
+`Facet.get_aesthetic_and_quality_batch` (processing/scorer.py:640-673), backed by libfacet_engine.so.
+
+  fn(PIL) -> Tensor[3,224,224]            open_clip eval transform, on the host with PIL like the reference's loader threads
+  m.encode_image(Tensor[B,3,224,224]) -> Tensor[B,768]
+  next(m.parameters()).dtype               (callers test for float16, scorer.py:658; multi_pass.py:519)
+  m.to()/.cpu()/.half()/.eval()
+The text tower (`encode_text`, tagger.py:73) is a SURVEY §8(f) "next" row and raises NotImplementedError.
+"""
+import numpy as np
+
+from ._lib import Engine, FE_MODEL_CLIP, FE_MODEL_AESTHETIC
+from .weights import synthetic_state_dict
+
+CLIP_MEAN = np.array([0.48145466, 0.4578275, 0.40821073], np.float32)
+CLIP_STD = np.array([0.26862954, 0.26130258, 0.27577711], np.float32)
+
+
+def clip_preprocess(pil_img):
+    """open_clip image_transform(is_train=False): bicubic shorter-side resize to 224, center crop, ToTensor, Normalize."""
+    import torch
+    from PIL import Image
+    img = pil_img.convert('RGB')
+    w, h = img.size
+    ow, oh = (224, int(224 * h / w)) if w <= h else (int(224 * w / h), 224)
+    img = img.resize((ow, oh), Image.BICUBIC)
+    top, left = int(round((oh - 224) / 2.0)), int(round((ow - 224) / 2.0))
+    a = np.asarray(img.crop((left, top, left + 224, top + 224)), np.float32) / 255.0
+    a = (a - CLIP_MEAN) / CLIP_STD
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+
+
+class CLIPImageModel:
+    def __init__(self, engine, state_dict):
+        self._engine, self._sd = engine, state_dict
+        self._resident()
+
+    def _resident(self):
+        if not self._engine.loaded(FE_MODEL_CLIP):
+            self._engine.load_weights(FE_MODEL_CLIP, self._sd)
+
+    def encode_image(self, x):
+        import torch
+        self._resident()
+        feat = self._engine.clip_encode_image(x.detach().float().cpu().numpy())
+        return torch.from_numpy(feat)
+
+    def encode_text(self, tokens):
+        raise NotImplementedError("CLIP text tower is not part of the engine yet (SURVEY.md §8f-3)")
+
+    def parameters(self):
+        import torch
+        yield torch.zeros(1, dtype=torch.float32)  # engine computes in fp32
+
+    def to(self, *a, **k):
+        if a and str(a[0]) == 'cpu':
+            return self.cpu()
+        self._resident()
+        return self
+
+    def cpu(self):
+        if self._engine.loaded(FE_MODEL_CLIP):
+            self._engine.unload(FE_MODEL_CLIP)
+        return self
+
+    def half(self):
+        return self
+
+    def eval(self):
+        return self
+
+
+def load_clip(engine=None, weights_path=None, synthetic_seed=9):
+    """-> {'model': CLIPImageModel, 'preprocess': fn} like ModelManager._load_clip (model_manager.py:127-148)."""
+    engine = engine or Engine(0)
+    if weights_path:
+        from .pyiqa_scorer import load_checkpoint
+        sd = load_checkpoint(weights_path)
+    else:
+        print("Warning: no CLIP checkpoint path given; using a seeded synthetic checkpoint")
+        sd = synthetic_state_dict('clip', synthetic_seed)
+    return {'model': CLIPImageModel(engine, sd), 'preprocess': clip_preprocess}
+
+
+class ClipAestheticScorer:
+    """`Facet.get_aesthetic_and_quality_batch` (scorer.py:640-673): one engine call for tower + normalise + MLP."""
+
+    def __init__(self, engine, clip_handle, aesthetic_state=None, synthetic_seed=9):
+        self._engine = engine
+        self.model, self.preprocess = clip_handle['model'], clip_handle['preprocess']
+        engine.load_weights(FE_MODEL_AESTHETIC, aesthetic_state or synthetic_state_dict('aesthetic', synthetic_seed))
+
+    def get_aesthetic_and_quality_batch(self, pil_images, clip_inputs=None):
+        import torch
+        inputs = clip_inputs if clip_inputs is not None else torch.stack([self.preprocess(im) for im in pil_images])
+        self.model._resident()
+        feat, emb, aes = self._engine.clip_encode_image(inputs.detach().float().cpu().numpy(), normalized=True,
+                                                        aesthetic=True)
+        return [(max(0.0, min(10.0, (float(aes[i]) + 1) * 5)), emb[i].astype(np.float32).tobytes(), None, 'clip-mlp')
+                for i in range(len(pil_images))]

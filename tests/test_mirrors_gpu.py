@@ -1,0 +1,53 @@
+"""GPU: the drop-in Python mirrors (reference call signatures) run on the engine and agree with the raw C-ABI results."""
+import numpy as np
+import pytest
+from PIL import Image
+
+from facet_amd.weights import synthetic_images
+
+pytestmark = pytest.mark.gpu
+
+
+def test_model_manager_lifecycle_and_scorers(engine):
+    from facet_amd.model_manager import ModelManager
+    from facet_amd.clip import ClipAestheticScorer
+    mm = ModelManager(config=None, engine=engine)
+    topiq = mm.load_model_only("topiq")
+    samp = mm.load_model_only("samp_net")
+    clip = mm.load_model_only("clip")
+    assert mm._cache_misses == 3 and set(mm.get_loaded_models()) == {"topiq", "samp_net", "clip"}
+    imgs = synthetic_images(3, 3, 160, 192)
+    pils = [Image.fromarray(a) for a in imgs]
+
+    s = topiq.score_batch(pils)                      # PyIQAScorer mirror: floats in [0,10]
+    assert len(s) == 3 and all(isinstance(v, float) and 0.0 <= v <= 10.0 for v in s)
+    raw = engine.topiq_score(imgs)
+    assert np.allclose(s, np.clip(raw, 0, 1) * 10, atol=1e-5)
+    assert abs(topiq.score_image(pils[1]) - s[1]) < 1e-4
+    assert topiq.score_batch([pils[0], "not an image"])[1] == 5.0   # per-image failure -> 5.0 (reference :251-253)
+
+    r = samp.score(imgs[0][..., ::-1].copy())        # ndarray = BGR, like the reference's img_cv
+    r2 = samp.score(pils[0])
+    assert r["pattern"] == r2["pattern"] and abs(r["comp_score"] - r2["comp_score"]) <= 0.01
+    assert set(r) == {"comp_score", "raw_score", "pattern", "pattern_index", "pattern_weights", "score_distribution",
+                      "attributes", "power_point_score"}
+    assert len(samp.score_batch(pils)) == 3
+
+    sc = ClipAestheticScorer(engine, clip)
+    out = sc.get_aesthetic_and_quality_batch(pils)
+    assert len(out) == 3 and all(len(o[1]) == 3072 and o[2] is None and o[3] == "clip-mlp" and 0 <= o[0] <= 10 for o in out)
+    emb = np.frombuffer(out[0][1], np.float32)
+    assert abs(np.linalg.norm(emb) - 1) < 1e-5
+    x = clip["preprocess"](pils[0])
+    f = clip["model"].encode_image(x[None])
+    assert tuple(f.shape) == (1, 768) and str(next(clip["model"].parameters()).dtype) == "torch.float32"
+    _, emb_gpu, _ = engine.clip_encode_images(imgs[:1])   # GPU preprocessing path vs host PIL preprocessing path
+    assert float((emb_gpu[0] * emb).sum()) > 1 - 1e-5
+
+    mm.unload_model("topiq")
+    assert not engine.loaded(0) and "topiq" not in mm.get_loaded_models()
+    again = mm.load_model_only("topiq")              # restored from the host cache (cache hit), same object
+    assert again is topiq and mm._cache_hits == 1 and engine.loaded(0)
+    assert abs(again.score_image(pils[1]) - s[1]) < 1e-4
+    mm.unload_all(); mm.evict_cpu_cache()
+    assert mm.get_loaded_models() == []
