@@ -58,7 +58,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--microbatch", type=int, default=8)
+    ap.add_argument("--microbatch", type=int, default=32)
+    ap.add_argument("--workload", choices=["topiq", "ensemble"], default="topiq",
+                    help="topiq = BASELINE.json configs[1]; ensemble = TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP")
     ap.add_argument("--cpu-sample", type=int, default=4, help="images for the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -76,13 +78,18 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from facet_amd import Engine
-    from facet_amd._lib import FE_MODEL_TOPIQ
+    from facet_amd._lib import (FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_AESTHETIC, FE_MODEL_SAMP, FE_MODEL_U2NETP)
     from facet_amd.weights import synthetic_state_dict
     from facet_amd.sharding import shard_range, gather_scores
 
     B, HW = args.batch, args.size
-    eng = Engine(local_rank, arena_bytes=(4 + 2 * args.microbatch) << 30)
+    eng = Engine(local_rank, arena_bytes=(4 + 2 * args.microbatch * max(1, (HW * HW) // (1024 * 1024))) << 30)
     eng.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", seed=3))
+    if args.workload == "ensemble":
+        eng.load_weights(FE_MODEL_CLIP, synthetic_state_dict("clip", seed=3))
+        eng.load_weights(FE_MODEL_AESTHETIC, synthetic_state_dict("aesthetic", seed=3))
+        eng.load_weights(FE_MODEL_U2NETP, synthetic_state_dict("u2netp", seed=3))
+        eng.load_weights(FE_MODEL_SAMP, synthetic_state_dict("samp_net", seed=3))
     eng.set_microbatch(args.microbatch)
 
     # this rank's shard of the global batch (weak scaling: B images per GPU), generated once, resident in HBM
@@ -103,6 +110,10 @@ def main():
         torch.cuda.synchronize()
 
     def step():
+        if args.workload == "ensemble":
+            rec, mask = eng.ensemble_score(images)      # [B, 789] per-image records
+            assert mask == 7
+            return gather_scores(rec, world, local_rank)
         scores = eng.topiq_score(images)
         return gather_scores(scores, world, local_rank)
 
@@ -118,7 +129,7 @@ def main():
     dt = time.perf_counter() - t0
     ev_ms = eng.timer_stop()
     flops = eng.flops()
-    assert allscores.shape == (B * world,) and np.isfinite(allscores).all()
+    assert allscores.shape[0] == B * world and np.isfinite(allscores).all()
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -133,8 +144,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"TOPIQ-NR (ResNet-50 pyramid + CFANet head) fp32, batch {B}/GPU, {HW}x{HW} RGB "
-                                   "(BASELINE.json configs[1])",
+            "config": {"workload": (f"TOPIQ-NR (ResNet-50 pyramid + CFANet head) fp32, batch {B}/GPU, {HW}x{HW} RGB "
+                                    "(BASELINE.json configs[1])") if args.workload == "topiq" else
+                                   (f"ensemble TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP fp32 (no InsightFace), "
+                                    f"batch {B}/GPU, {HW}x{HW} RGB"),
                        "global_batch": B * world, "image_size": HW, "microbatch": args.microbatch,
                        "parallelism": f"image-sharded x{world}, RCCL all-gather of scores",
                        "weights": "seeded synthetic checkpoint (no weight files offline)"},
@@ -144,7 +157,7 @@ def main():
                          "flops_per_image": round(flops / (B * args.steps), 1),
                          "event_ms": round(ev_ms, 3)},
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and args.workload == "topiq":
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, HW, 3)
         print(json.dumps(out), flush=True)
     if world > 1:

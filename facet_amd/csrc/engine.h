@@ -134,7 +134,7 @@ struct Ctx {
 // pre-norm transformer layers of pyiqa's CFANet (DETR-style) [DEP-KNOWLEDGE]
 struct EncLayerW { MHAW attn; ConvW lin1, lin2; LayerNormW n1, n2; };
 struct DecLayerW { MHAW cross; ConvW lin1, lin2; LayerNormW n1, n2, n3; };
-struct GatedConvW { ConvW split_x1, split_x2, w0, w2, w4; };
+struct GatedConvW { ConvW split_x1, w0, w2, w4; };  // w0 = weight_blk[0] composed with the x2 half of splitconv
 
 struct TopiqModel {
   DeviceWeights dw;

@@ -56,6 +56,17 @@ static ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector
           packed[(size_t)co * c.Kp + (size_t)(kh * c.KW + kw) * c.CinPad + ci] =
               w.data[(((size_t)co * c.Cin + ci) * c.KH + kh) * c.KW + kw];
   c.w = dw.upload(packed);
+  if (c.Cout <= 2 && c.KH * c.KW > 1 && c.CinPad % 16 == 0) {
+    // tap-decomposed form: z[pixel][tap*Cout+co] = <x[pixel], w[co][tap]> as a 1x1 conv, neighbours summed afterwards
+    const int T = c.KH * c.KW * c.Cout;
+    c.KpT = (c.CinPad + CONV_KALIGN - 1) / CONV_KALIGN * CONV_KALIGN;
+    std::vector<float> tp((size_t)T * c.KpT, 0.f);
+    for (int t = 0; t < c.KH * c.KW; ++t)
+      for (int co = 0; co < c.Cout; ++co)
+        for (int ci = 0; ci < c.Cin; ++ci)
+          tp[(size_t)(t * c.Cout + co) * c.KpT + ci] = w.data[(((size_t)co * c.Cin + ci) * c.KH + t / c.KW) * c.KW + t % c.KW];
+    c.wtap = dw.upload(tp);
+  }
   if (scale) c.scale = dw.upload(*scale);
   if (shift) c.shift = dw.upload(*shift);
   return c;
@@ -146,6 +157,23 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
   FE_CHECK(y.pixels() < (1ull << 31), "conv: M too large");
   p.act = o.act; p.res_after_act = o.res_after_act;
   p.variant = c.force_variant;
+  if (w.wtap && o.sh == 1 && o.sw == 1 && !o.res && !o.gate && p.variant == 0 && y.h == x.h && y.w == x.w) {
+    // narrow spatial conv (Cout <= 2): 1x1 conv to per-tap partials on the matrix cores + a gather-sum pass
+    const int T = w.KH * w.KW * w.Cout, Tp = (T + 3) & ~3;
+    const size_t mark = c.arena.mark();
+    Tensor z = c.arena.tensor(x.n, x.h, x.w, Tp);
+    ConvParams q{};
+    q.x = x.p; q.ldx = x.ld; q.w = w.wtap; q.y = z.p; q.ldy = Tp;
+    q.N = x.n; q.H = x.h; q.W = x.w; q.Cin = w.CinPad; q.Ho = x.h; q.Wo = x.w; q.Cout = T;
+    q.KH = q.KW = 1; q.sh = q.sw = q.dh = q.dw = 1;
+    q.K = w.CinPad; q.Kp = w.KpT; q.M = (int)x.pixels();
+    launch_conv(q, c.stream);
+    launch_tap_gather(z.p, Tp, x.n, x.h, x.w, w.KH, w.KW, o.ph, o.pw, o.dh, o.dw, w.Cout, w.scale, w.shift, o.act, y.p,
+                      y.ld, y.h, y.w, c.stream);
+    c.arena.rewind(mark);
+    c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * p.Cout;
+    return;
+  }
   if (c.profile) {
     hipEvent_t e0, e1;
     FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));

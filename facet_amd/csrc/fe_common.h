@@ -128,6 +128,9 @@ struct ConvW {
   float* scale = nullptr;  // [Cout] or null
   float* shift = nullptr;  // [Cout] or null
   int Cout = 0, Cin = 0, CinPad = 0, KH = 1, KW = 1, K = 0, Kp = 0;
+  // Cout <= 2 spatial kernels also carry a tap-decomposed form: rows (tap, co) of a 1x1 conv [KH*KW*Cout][KpT]
+  float* wtap = nullptr;
+  int KpT = 0;
 };
 
 struct ConvOpts {
@@ -141,6 +144,7 @@ struct ConvOpts {
 constexpr int CONV_KALIGN = 32;  // Kp is a multiple of this (covers BK = 16 and 32)
 
 void launch_conv(const ConvParams& p, hipStream_t s);
+void launch_conv_narrow(const ConvParams& p, hipStream_t s);            // Cout <= 4, no MFMA (kernels_misc.hip)
 void launch_conv_dma(const ConvParams& p, int tile, hipStream_t s);  // LDS-DMA fast path (kernels_conv_dma.hip)
 double conv_flops(const ConvParams& p);
 
@@ -162,6 +166,10 @@ void launch_bilinear(const Tensor& x, const Tensor& y, hipStream_t s);
 // adaptive average pool NHWC -> NHWC (torch semantics: start=floor(i*H/Ho), end=ceil((i+1)*H/Ho))
 void launch_adaptive_avgpool(const Tensor& x, const Tensor& y, hipStream_t s);
 // y = act(x) elementwise / y = x + r
+// y[n,oh,ow,co] = act(scale*sum_tap z[n, oh-ph+kh*dh, ow-pw+kw*dw, tap*Cout+co] + shift)  (stride 1)
+void launch_tap_gather(const float* z, int ldz, int n, int h, int w, int kh, int kw, int ph, int pw, int dh, int dw,
+                       int cout, const float* scale, const float* shift, int act, float* y, int ldy, int ho, int wo,
+                       hipStream_t s);
 void launch_sigmoid(const Tensor& x, const Tensor& y, hipStream_t s);
 void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s);
 // LayerNorm over last dim of a [rows][d] matrix (eps inside sqrt, biased variance)

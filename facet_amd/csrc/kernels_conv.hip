@@ -314,8 +314,9 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
   const bool f32 = bk32 && (p.Cin % 32 == 0);
   // Tile choice: 128x128 for wide outputs, 256x64 / 256x32 for narrow ones; problems too small to give every
   // CU a 128x128 tile drop to 64x64 tiles (4x the workgroups).
-  if (q.variant > 10 && q.variant < 20) { launch_conv_dma(q, q.variant - 10, s); return; }
+  if (q.variant % 100 > 10 && q.variant % 100 < 20) { q.dbg = q.variant / 100; launch_conv_dma(q, q.variant % 100 - 10, s); return; }
   if (q.variant > 0) { q.dbg = q.variant / 100; q.variant %= 100; launch_forced(q, s); return; }
+  if (p.Cout <= 4 && q.batch <= 1 && !p.gate && q.variant == 0) { launch_conv_narrow(q, s); return; }
   static const bool no_dma = getenv("FE_NO_DMA") != nullptr;
   if (!no_dma && p.Cin % 16 == 0 && p.KH * p.KW < 64) {
     const long long wg = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * q.batch;

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4))) v
       if (16 * (4 * j + wave) < BM) {
         const bool ok = (amask[j] >> tap) & 1ull;
         const char* src = ok ? abase[j] + tb : zpage;
+        if (p.dbg & 8) src = reinterpret_cast<const char*>(p.x) + lane * 16;   // timing experiment: L1-resident source
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ab + 256 * (4 * j + wave)), 16, 0, 0);
       }
     }
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4))) v
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
       if (16 * (4 * j + wave) < BN)
-        __builtin_amdgcn_global_load_lds((gptr_t)(bbase[j] + tbb), (lptr_t)(Bb + 256 * (4 * j + wave)), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)((p.dbg & 8) ? reinterpret_cast<const char*>(p.w) + lane * 16 : bbase[j] + tbb), (lptr_t)(Bb + 256 * (4 * j + wave)), 16, 0, 0);
     }
     ci += BK;
     if (ci >= p.Cin) {
@@ -135,67 +136,85 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4))) v
   const int fo0 = ((h ^ sw) << 2), fo1 = fo0 ^ 8;
   const int aoff = (wm * TM * 32 + r) * BK, boff = BM * BK + (wn * TN * 32 + r) * BK;
 
-  // 3-slab ring: slabs t+1 and t+2 are in flight while slab t is consumed. A wave waits only for its OWN pieces
-  // of slab t (counted vmcnt leaves the newer slab's pieces outstanding), then the raw barrier publishes the slab
-  // and retires everybody's reads of the buffer that slab t+2 is about to overwrite.
-  constexpr int NPW_A = BM / 64;                       // pieces every wave issues per slab (BM % 64 == 0)
+  // 3-slab LDS ring + register double-buffered fragments:
+  //   iteration t:  wait own pieces of slab t+1 (counted vmcnt keeps slab t+2 in flight) -> raw barrier (publishes
+  //   slab t+1, retires every wave's reads of slab t) -> DMA slab t+3 into slab t's buffer -> ds_read fragments of
+  //   slab t+1 into the other register set -> 32 MFMAs on the fragments of slab t (the LDS reads land in their shadow).
+  // Fragment reads are inline asm on purpose: hipcc orders every C++ LDS read behind ALL outstanding LDS-DMA
+  // (s_waitcnt vmcnt(0)), which would drain the ring each step.
+  constexpr int NPW_A = BM / 64;
   static_assert(BM % 64 == 0, "A pieces must be uniform over waves");
   const int npw = NPW_A + ((16 * wave < BN) ? 1 : 0) + ((BN > 64 && 16 * (4 + wave) < BN) ? 1 : 0) +
                   ((BN > 128 && 16 * (8 + wave) < BN) ? 1 : 0) + ((BN > 192 && 16 * (12 + wave) < BN) ? 1 : 0);
+  auto wait_vm = [&](int n) {   // n is wave-uniform
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
   const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
+  v4f fa[2][2 * TM], fb[2][2 * TN];   // [register set][fragment]; indices are compile-time everywhere below
+#define FE_READ_FRAGS(SET, SLOT)                                                                                   \
+  {                                                                                                                \
+    const unsigned sb_ = lds_base + (unsigned)((SLOT) * SLAB * 4);                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                               \
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET][2 * i]) : "v"(sb_ + (unsigned)((aoff + i * 32 * BK + fo0) * 4)));     \
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET][2 * i + 1]) : "v"(sb_ + (unsigned)((aoff + i * 32 * BK + fo1) * 4))); \
+    }                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                               \
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET][2 * j]) : "v"(sb_ + (unsigned)((boff + j * 32 * BK + fo0) * 4)));     \
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET][2 * j + 1]) : "v"(sb_ + (unsigned)((boff + j * 32 * BK + fo1) * 4))); \
+    }                                                                                                              \
+  }
+#define FE_MFMA_BURST(SET)                                                                                         \
+  _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                 \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                             \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i + hh].x, fb[SET][2 * j + hh].x, acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i + hh].y, fb[SET][2 * j + hh].y, acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i + hh].z, fb[SET][2 * j + hh].z, acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i + hh].w, fb[SET][2 * j + hh].w, acc[i][j], 0, 0, 0); \
+      }
+  // one K-step: fragments of slab kt are in register set CUR
+#define FE_STEP(CUR, NXT, KT)                                                                                      \
+  {                                                                                                                \
+    const int kt_ = (KT);                                                                                          \
+    if (kt_ + 1 < nk) {                                                                                            \
+      wait_vm(kt_ + 2 < nk ? npw : 0);                                                                             \
+      __builtin_amdgcn_s_barrier();                                                                                \
+      if (kt_ + 3 < nk) issue(kt_ + 3, kt_ % 3);                                                                   \
+      FE_READ_FRAGS(NXT, (kt_ + 1) % 3)                                                                            \
+    }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    FE_MFMA_BURST(CUR)                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+  }
+
   issue(0, 0);
   if (nk > 1) issue(1, 1);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      // leave the newest slab (npw pieces of this wave) in flight
-      if (npw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if (npw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else if (npw == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (npw == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else if (npw == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (npw == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
-    // Fragment reads are inline asm on purpose: hipcc orders every C++ LDS read behind ALL outstanding LDS-DMA
-    // (s_waitcnt vmcnt(0)), which would drain the ring each step. The counted vmcnt + barrier above already
-    // guarantee slab kt has landed; the reads are retired by the explicit lgkmcnt(0) below.
-    const unsigned sb = lds_base + (unsigned)((kt % 3) * SLAB * 4);
-    v4f a0[TM], a1[TM], b0[TN], b1[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      asm volatile("ds_read_b128 %0, %1" : "=v"(a0[i]) : "v"(sb + (unsigned)((aoff + i * 32 * BK + fo0) * 4)));
-      asm volatile("ds_read_b128 %0, %1" : "=v"(a1[i]) : "v"(sb + (unsigned)((aoff + i * 32 * BK + fo1) * 4)));
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      asm volatile("ds_read_b128 %0, %1" : "=v"(b0[j]) : "v"(sb + (unsigned)((boff + j * 32 * BK + fo0) * 4)));
-      asm volatile("ds_read_b128 %0, %1" : "=v"(b1[j]) : "v"(sb + (unsigned)((boff + j * 32 * BK + fo1) * 4)));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].x, b0[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].y, b0[j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].z, b0[j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].w, b0[j].w, acc[i][j], 0, 0, 0);
-      }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].x, b1[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].y, b1[j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].z, b1[j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i].w, b1[j].w, acc[i][j], 0, 0, 0);
-      }
+  if (nk > 2) issue(2, 2);
+  wait_vm(nk > 2 ? 2 * npw : (nk > 1 ? npw : 0));
+  __builtin_amdgcn_s_barrier();
+  FE_READ_FRAGS(0, 0)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt < nk; kt += 2) {
+    FE_STEP(0, 1, kt)
+    if (kt + 1 < nk) FE_STEP(1, 0, kt + 1)
   }
+#undef FE_STEP
+#undef FE_MFMA_BURST
+#undef FE_READ_FRAGS
   __syncthreads();   // all fragment reads retired before the epilogue reuses the slabs as staging
 
   // ---- epilogue (same as conv_igemm_kernel): transpose through a wave-private LDS region ------------------

@@ -206,6 +206,105 @@ void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s
   FE_HIP(hipGetLastError());
 }
 
+// ---- narrow-output convolution (Cout <= 4): HBM-bound dot products, no matrix cores -------------------------
+// 16 lanes share one output pixel (each owns 4 input channels per 64-channel chunk), 4 pixels per wave instruction;
+// partial sums are reduced with xor-shuffles. Used for the Cout=1 gate / side / fuse convolutions (TOPIQ GatedConv
+// weight_blk[4], U2-Net-P side1-6 + outconv) where a 32-wide MFMA tile would waste 31/32 of the matrix work.
+template <int CO>
+__global__ void conv_narrow_kernel(const ConvParams p) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 15, grp = lane >> 4;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const int HoWo = p.Ho * p.Wo;
+  for (long long m4 = wave * 4; m4 < p.M; m4 += nwaves * 4) {
+    const long long m = m4 + grp;
+    const bool mv = m < p.M;
+    const int mm = mv ? (int)m : 0;
+    const int nimg = mm / HoWo;
+    const int rem = mm - nimg * HoWo;
+    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+    for (int kh = 0; kh < p.KH; ++kh) {
+      const int ih = oh * p.sh - p.ph + kh * p.dh;
+      for (int kw = 0; kw < p.KW; ++kw) {
+        const int iw = ow * p.sw - p.pw + kw * p.dw;
+        const bool ok = mv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        const float* xp = p.x + (((size_t)nimg * p.H + (ok ? ih : 0)) * p.W + (ok ? iw : 0)) * p.ldx;
+        const float* wp = p.w + (size_t)(kh * p.KW + kw) * p.Cin;
+        for (int c = sub * 4; c < p.Cin; c += 64) {
+          float4 xv = *reinterpret_cast<const float4*>(xp + c);
+          if (!ok) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int o = 0; o < CO; ++o) {
+            const float4 wv = *reinterpret_cast<const float4*>(wp + (size_t)o * p.ldw + c);
+            acc[o] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      float v = acc[o];
+      v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+      if (sub == 0 && mv && o < p.Cout) {
+        v = v * (p.scale ? p.scale[o] : 1.f) + (p.shift ? p.shift[o] : 0.f);
+        if (p.res && !p.res_after_act) v += p.res[(size_t)m * p.ldr + o];
+        if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+        if (p.res && p.res_after_act) v += p.res[(size_t)m * p.ldr + o];
+        p.y[(size_t)m * p.ldy + o] = v;
+      }
+    }
+  }
+}
+void launch_conv_narrow(const ConvParams& p, hipStream_t s) {
+  FE_CHECK(p.Cout <= 4 && p.Cin % 4 == 0 && p.batch <= 1 && !p.gate, "conv_narrow: unsupported problem");
+  const int blocks = grid_for((size_t)((p.M + 3) / 4) * 64);
+  if (p.Cout == 1) hipLaunchKernelGGL(conv_narrow_kernel<1>, dim3(blocks), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(conv_narrow_kernel<4>, dim3(blocks), dim3(256), 0, s, p);
+  FE_HIP(hipGetLastError());
+}
+
+// ---- second half of the tap-decomposed narrow convolution: sum the per-tap partial products of the neighbours ----
+__global__ void tap_gather_kernel(const float* __restrict__ z, int ldz, int n, int h, int w, int kh, int kw, int ph, int pw,
+                                  int dh, int dw, int cout, const float* __restrict__ scale, const float* __restrict__ shift,
+                                  int act, float* __restrict__ y, int ldy, int ho, int wo) {
+  const size_t total = (size_t)n * ho * wo * cout;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = i % cout;
+    size_t pix = i / cout;
+    const int ow = pix % wo; pix /= wo;
+    const int oh = pix % ho;
+    const size_t img = pix / ho;
+    float acc = 0.f;
+    for (int a = 0; a < kh; ++a) {
+      const int ih = oh - ph + a * dh;
+      if ((unsigned)ih >= (unsigned)h) continue;
+      for (int b = 0; b < kw; ++b) {
+        const int iw = ow - pw + b * dw;
+        if ((unsigned)iw >= (unsigned)w) continue;
+        acc += z[((img * h + ih) * w + iw) * ldz + (a * kw + b) * cout + co];
+      }
+    }
+    float v = acc * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+    if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    else if (act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+    y[((img * ho + oh) * wo + ow) * ldy + co] = v;
+  }
+}
+void launch_tap_gather(const float* z, int ldz, int n, int h, int w, int kh, int kw, int ph, int pw, int dh, int dw,
+                       int cout, const float* scale, const float* shift, int act, float* y, int ldy, int ho, int wo,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(tap_gather_kernel, dim3(grid_for((size_t)n * ho * wo * cout)), dim3(256), 0, s, z, ldz, n, h, w, kh, kw,
+                     ph, pw, dh, dw, cout, scale, shift, act, y, ldy, ho, wo);
+  FE_HIP(hipGetLastError());
+}
+
 // ---- LayerNorm: one wave per row, two-pass (mean, then centred variance) in registers ------------------
 __global__ void layernorm_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                  const float* __restrict__ g, const float* __restrict__ b, int rows, int d, float eps) {

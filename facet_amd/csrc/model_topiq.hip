@@ -6,6 +6,7 @@
 // (use_ref=False, inter_dim=256, 4 heads, 1 layer per block, GELU, pre-norm) [DEP-KNOWLEDGE] and is
 // parity-checked against oracle/topiq.py, the same restatement in torch-CPU ("parity unpinned").
 #include "engine.h"
+#include <algorithm>
 #include <cmath>
 
 namespace fe {
@@ -42,8 +43,31 @@ void build_topiq_head(TopiqModel& m, const WeightStore& ws) {
     FE_CHECK(W.shape[0] == 2 * dim, "splitconv %d shape", i);
     HostTensor W2; W2.shape = {2 * dim, dim}; W2.data = W.data;  // [2dim][dim][1][1] == [2dim][dim]
     m.gate[i].split_x1 = build_linear_rows(m.dw, W2, &B, 0, dim);
-    m.gate[i].split_x2 = build_linear_rows(m.dw, W2, &B, dim, dim);
-    m.gate[i].w0 = build_conv(m.dw, ws, g + ".weight_blk.0", "", true);
+    {
+      // x2 = splitconv(x)[dim:2dim] feeds weight_blk[0] (a 1x1 conv) with no nonlinearity in between, so the two
+      // linear maps are composed once here (in double): w0(x2) = (W0 . Wx2) x + (W0 . bx2 + b0). Saves one
+      // dim x dim 1x1 convolution and a full-resolution tensor round trip per level.
+      const HostTensor& W0 = ws.get(g + ".weight_blk.0.weight");   // [64][dim][1][1]
+      const HostTensor& B0 = ws.get(g + ".weight_blk.0.bias");
+      const int mid = (int)W0.shape[0];
+      FE_CHECK((int)W0.shape[1] == dim, "weight_blk.0 of level %d expects %d inputs", i, dim);
+      HostTensor We; We.shape = {mid, dim}; We.data.resize((size_t)mid * dim);
+      HostTensor Be; Be.shape = {mid}; Be.data.resize(mid);
+      std::vector<double> row(dim);
+      for (int o = 0; o < mid; ++o) {
+        std::fill(row.begin(), row.end(), 0.0);
+        double bacc = B0.data[o];
+        for (int k = 0; k < dim; ++k) {
+          const double w0k = W0.data[(size_t)o * dim + k];
+          const float* wx = &W.data[(size_t)(dim + k) * dim];   // row (dim + k) of splitconv = x2 channel k
+          for (int c = 0; c < dim; ++c) row[c] += w0k * wx[c];
+          bacc += w0k * B.data[dim + k];
+        }
+        for (int c = 0; c < dim; ++c) We.data[(size_t)o * dim + c] = (float)row[c];
+        Be.data[o] = (float)bacc;
+      }
+      m.gate[i].w0 = build_linear_rows(m.dw, We, &Be, 0, mid);
+    }
     m.gate[i].w2 = build_conv(m.dw, ws, g + ".weight_blk.2", "", true);
     m.gate[i].w4 = build_conv(m.dw, ws, g + ".weight_blk.4", "", true);
     m.dim_reduce[i] = build_conv(m.dw, ws, "dim_reduce." + std::to_string(i) + ".0", "", true);
@@ -160,10 +184,8 @@ void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<Tensor>& feats,
     const size_t mark = c.arena.mark();
     const Tensor& f = feats[i];
     const GatedConvW& g = m.gate[i];
-    ConvOpts plain;
-    Tensor x2 = conv_new(c, g.split_x2, f, plain);
     ConvOpts o0; o0.act = ACT_GELU;
-    Tensor wa = conv_new(c, g.w0, x2, o0);
+    Tensor wa = conv_new(c, g.w0, f, o0);    // = GELU(weight_blk[0](x2)) with x2 folded in (see build_topiq_head)
     ConvOpts o2; o2.act = ACT_GELU; o2.ph = o2.pw = 1;
     Tensor wb = conv_new(c, g.w2, wa, o2);
     ConvOpts o4; o4.act = ACT_SIGMOID; o4.ph = o4.pw = 1;
