@@ -322,7 +322,7 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
     const long long wg = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * q.batch;
     int tile;
     if (p.Cout > 64) tile = wg < 384 ? 4 : 1;
-    else if (p.Cout > 32) tile = wg < 192 ? 4 : 2;
+    else if (p.Cout > 32) tile = wg < 192 ? 4 : 7;   // 128x64: 4 waves/SIMD beats 256x64 on every N<=64 layer measured
     else tile = 3;
     launch_conv_dma(q, tile, s);
     return;

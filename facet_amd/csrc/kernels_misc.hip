@@ -371,8 +371,60 @@ __global__ void softmax_rows_pad_kernel(float* __restrict__ x, int ld, int rows,
     for (int i = lane; i < ld; i += 64) xr[i] = i < d ? xr[i] * inv : 0.f;
   }
 }
+// Register-resident variant (ld <= 64*NV*4, ld % 4 == 0): one 16-B read and one 16-B write per element group.
+template <int NV>
+__global__ void softmax_rows_pad_reg_kernel(float* __restrict__ x, int ld, int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int row = wave; row < rows; row += nwaves) {
+    float4* xr = reinterpret_cast<float4*>(x + (size_t)row * ld);
+    float4 v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (lane + 64 * k) * 4;
+      if (c < ld) {
+        v[k] = xr[lane + 64 * k];
+        if (c + 0 < d) mx = fmaxf(mx, v[k].x);
+        if (c + 1 < d) mx = fmaxf(mx, v[k].y);
+        if (c + 2 < d) mx = fmaxf(mx, v[k].z);
+        if (c + 3 < d) mx = fmaxf(mx, v[k].w);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (lane + 64 * k) * 4;
+      if (c < ld) {
+        v[k].x = c + 0 < d ? expf(v[k].x - mx) : 0.f;
+        v[k].y = c + 1 < d ? expf(v[k].y - mx) : 0.f;
+        v[k].z = c + 2 < d ? expf(v[k].z - mx) : 0.f;
+        v[k].w = c + 3 < d ? expf(v[k].w - mx) : 0.f;
+        sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (lane + 64 * k) * 4;
+      if (c < ld) xr[lane + 64 * k] = make_float4(v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
+    }
+  }
+}
 void launch_softmax_rows_pad(float* x, int ld, int rows, int d, hipStream_t s) {
-  hipLaunchKernelGGL(softmax_rows_pad_kernel, dim3(grid_for((size_t)rows * 64)), dim3(256), 0, s, x, ld, rows, d);
+  const bool vec = (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
+  const int blocks = grid_for((size_t)rows * 64);
+  if (vec && ld <= 64 * 4 * 2)
+    hipLaunchKernelGGL(softmax_rows_pad_reg_kernel<2>, dim3(blocks), dim3(256), 0, s, x, ld, rows, d);
+  else if (vec && ld <= 64 * 4 * 8)
+    hipLaunchKernelGGL(softmax_rows_pad_reg_kernel<8>, dim3(blocks), dim3(256), 0, s, x, ld, rows, d);
+  else
+    hipLaunchKernelGGL(softmax_rows_pad_kernel, dim3(blocks), dim3(256), 0, s, x, ld, rows, d);
   FE_HIP(hipGetLastError());
 }
 __global__ void add_rows_bcast_kernel(float* __restrict__ y, int ldy, const float* __restrict__ pos, size_t rows, int L, int d) {
