@@ -65,6 +65,7 @@ SIGNATURES = {
     "fe_op_adaptive_avgpool": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          _f32p]),
     "fe_op_layernorm": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_float, _f32p]),
+    "fe_set_conv_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "fe_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int] * 12 + [_f32p]),
     "fe_topiq_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_topiq_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
@@ -268,6 +269,9 @@ class Engine:
         y = np.empty_like(x)
         self._ck(self.lib.fe_op_layernorm(self.h, xp, rows, d, gp, bp, eps, y.ctypes.data_as(_f32p)))
         return y
+
+    def set_conv_variant(self, v):
+        self._ck(self.lib.fe_set_conv_variant(self.h, int(v)))
 
     def bench_conv(self, n, h, w, cin, cout, k, stride=1, pad=0, res=False, act="relu", variant=0, iters=10):
         ms = C.c_float()

@@ -91,6 +91,12 @@ int fe_set_microbatch(fe_ctx* ctx, int n) {
   FE_API_END(ctx)
 }
 
+int fe_set_conv_variant(fe_ctx* ctx, int variant) {
+  FE_API_BEGIN(ctx)
+  ctx->c.force_variant = variant;
+  FE_API_END(ctx)
+}
+
 int fe_dev_alloc(fe_ctx* ctx, size_t bytes, void** d_out) {
   FE_API_BEGIN(ctx)
   FE_CHECK(d_out != nullptr, "null out");

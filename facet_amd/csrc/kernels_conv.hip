@@ -314,14 +314,16 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
   const bool f32 = bk32 && (p.Cin % 32 == 0);
   // Tile choice: 128x128 for wide outputs, 256x64 / 256x32 for narrow ones; problems too small to give every
   // CU a 128x128 tile drop to 64x64 tiles (4x the workgroups).
-  if (q.variant % 100 > 10 && q.variant % 100 < 20) { q.dbg = q.variant / 100; launch_conv_dma(q, q.variant % 100 - 10, s); return; }
+  if (q.variant % 100 > 10 && q.variant % 100 < 40) { q.dbg = q.variant / 100; launch_conv_dma(q, (q.variant % 100 > 20) ? q.variant % 100 : q.variant % 100 - 10, s); return; }
   if (q.variant > 0) { q.dbg = q.variant / 100; q.variant %= 100; launch_forced(q, s); return; }
   if (p.Cout <= 4 && q.batch <= 1 && !p.gate && q.variant == 0) { launch_conv_narrow(q, s); return; }
   static const bool no_dma = getenv("FE_NO_DMA") != nullptr;
-  if (!no_dma && p.Cin % 16 == 0 && p.KH * p.KW < 64) {
+  const unsigned long long xspan = ((unsigned long long)p.N * p.H * p.W - 1) * (unsigned long long)p.ldx * 4 + (unsigned long long)p.Cin * 4;
+  const unsigned long long wspan = ((unsigned long long)p.Cout - 1) * (unsigned long long)q.ldw * 4 + (unsigned long long)p.Kp * 4;
+  if (!no_dma && p.Cin % 16 == 0 && p.KH * p.KW < 64 && xspan < 0xFFFFFF00ull && wspan < 0xFFFFFF00ull) {
     const long long wg = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * q.batch;
     int tile;
-    if (p.Cout > 64) tile = wg < 384 ? 4 : 1;
+    if (p.Cout > 64) tile = wg < 384 ? 4 : (p.K <= 256 ? 7 : 1);   // short-K layers are bandwidth-bound: favour occupancy
     else if (p.Cout > 32) tile = wg < 192 ? 4 : 7;   // 128x64: 4 waves/SIMD beats 256x64 on every N<=64 layer measured
     else tile = 3;
     launch_conv_dma(q, tile, s);

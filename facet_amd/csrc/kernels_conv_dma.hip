@@ -10,13 +10,12 @@
 //   * per K-step address work is one 64-bit add of a block-uniform tap offset to a per-row base pointer.
 // Three-slab LDS ring: two slabs are in flight while one is consumed (counted vmcnt + one raw s_barrier per K-step).
 #include "fe_common.h"
+#include <cstdlib>
 
 namespace fe {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
-
-__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
 __device__ __forceinline__ float apply_act_d(float v, int act) {
   if (act == ACT_RELU) return v > 0.f ? v : 0.f;
@@ -57,7 +56,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4))) v
   // ---- DMA source coordinates (per lane, fixed for the whole K loop) -------------------------------------
   const int rsub = lane >> 2, slot = lane & 3;
   const int gofs = (slot ^ ((rsub >> 2) & 3)) * 4;   // source chunk (floats) after the swizzle
-  const char* abase[AI];
+  unsigned aoffs[AI];          // byte offset of the row's (kh=0,kw=0,ci=0) element from p.x (buffer addressing)
   unsigned long long amask[AI];
   const int HoWo = p.Ho * p.Wo;
   const int ntaps = p.KH * p.KW;
@@ -72,7 +71,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4))) v
     const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
     const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
     const long long pix = ((long long)nimg * p.H + ih0) * p.W + iw0;
-    abase[j] = reinterpret_cast<const char*>(p.x + pix * p.ldx + gofs);
+    aoffs[j] = (unsigned)((pix * p.ldx + gofs) * 4);
     unsigned long long mk = 0;
     if (valid) {
       for (int tp = 0; tp < ntaps; ++tp) {
@@ -83,15 +82,18 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4))) v
     }
     amask[j] = mk;
   }
-  const char* bbase[BI];
+  unsigned boffs[BI];
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
     const int row = 16 * (4 * j + wave) + rsub;
     int n = n0 + row;
     if (n > p.Cout - 1) n = p.Cout - 1;   // columns past Cout are computed on a valid row and discarded
-    bbase[j] = reinterpret_cast<const char*>(p.w + (size_t)n * p.ldw + gofs);
+    boffs[j] = (unsigned)(((size_t)n * p.ldw + gofs) * 4);
   }
-  const char* zpage = reinterpret_cast<const char*>(g_zero_page);
+  // Buffer addressing (p.buf_ok: both operands span < 4 GiB): out-of-range offsets read as zero in hardware, so a
+  // padding tap is one v_cndmask to an out-of-range offset instead of a 64-bit pointer select to a zero page.
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_span, 0x00020000);
 
   // block-uniform running tap state
   int tap = 0, kh = 0, kw = 0, ci = 0;
@@ -101,25 +103,26 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4))) v
     float* Ab = smem + buf * SLAB;
     float* Bb = Ab + BM * BK;
     const int tb = ((kh * p.dh * p.W + kw * p.dw) * p.ldx + ci) * 4;   // byte offset of this tap/channel slab
+    {
 #pragma unroll
-    for (int j = 0; j < AI; ++j) {
-      if (16 * (4 * j + wave) < BM) {
-        const bool ok = (amask[j] >> tap) & 1ull;
-        const char* src = ok ? abase[j] + tb : zpage;
-        if (p.dbg & 8) src = reinterpret_cast<const char*>(p.x) + lane * 16;   // timing experiment: L1-resident source
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ab + 256 * (4 * j + wave)), 16, 0, 0);
+      for (int j = 0; j < AI; ++j) {
+        if (16 * (4 * j + wave) < BM) {
+          const bool ok = (amask[j] >> tap) & 1ull;
+          const unsigned off = ok ? aoffs[j] + (unsigned)tb : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(Ab + 256 * (4 * j + wave)), 16, (int)off, 0, 0, 0);
+        }
       }
-    }
-    const int tbb = kt * (BK * 4);
+      const int tbb2 = kt * (BK * 4);
 #pragma unroll
-    for (int j = 0; j < BI; ++j) {
-      if (16 * (4 * j + wave) < BN)
-        __builtin_amdgcn_global_load_lds((gptr_t)((p.dbg & 8) ? reinterpret_cast<const char*>(p.w) + lane * 16 : bbase[j] + tbb), (lptr_t)(Bb + 256 * (4 * j + wave)), 16, 0, 0);
-    }
-    ci += BK;
-    if (ci >= p.Cin) {
-      ci = 0; ++tap;
-      if (++kw == p.KW) { kw = 0; ++kh; }
+      for (int j = 0; j < BI; ++j) {
+        if (16 * (4 * j + wave) < BN)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(Bb + 256 * (4 * j + wave)), 16, (int)boffs[j], tbb2, 0, 0);
+      }
+      ci += BK;
+      if (ci >= p.Cin) {
+        ci = 0; ++tap;
+        if (++kw == p.KW) { kw = 0; ++kh; }
+      }
     }
   };
 
@@ -303,8 +306,15 @@ static void launch_dma_variant(const ConvParams& p, hipStream_t s) {
 }
 
 // tile: 1 = 128x128, 2 = 256x64, 3 = 256x32, 4 = 64x64, 7 = 128x64
-void launch_conv_dma(const ConvParams& p, int tile, hipStream_t s) {
-  FE_CHECK(p.Cin % 16 == 0 && p.KH * p.KW < 64, "conv_dma: needs Cin %% 16 == 0 and < 64 taps");
+void launch_conv_dma(const ConvParams& p0, int tile, hipStream_t s) {
+  FE_CHECK(p0.Cin % 16 == 0 && p0.KH * p0.KW < 64, "conv_dma: needs Cin %% 16 == 0 and < 64 taps");
+  ConvParams p = p0;
+  const unsigned long long xs = ((unsigned long long)p.N * p.H * p.W - 1) * (unsigned long long)p.ldx * 4 + (unsigned long long)p.Cin * 4;
+  const unsigned long long ws = ((unsigned long long)p.Cout - 1) * (unsigned long long)p.ldw * 4 + (unsigned long long)p.Kp * 4;
+  static const bool no_buf = getenv("FE_NO_BUF") != nullptr;
+  p.buf_ok = !no_buf && xs < 0xFFFFFF00ull && ws < 0xFFFFFF00ull;
+  FE_CHECK(p.buf_ok, "conv_dma: operand spans exceed 32-bit buffer addressing (caller must use the register-staged kernel)");
+  p.x_span = (unsigned)xs; p.w_span = (unsigned)ws;
   switch (tile) {
     case 1: launch_dma_variant<2, 2, 2, 2>(p, s); break;
     case 2: launch_dma_variant<4, 1, 2, 2>(p, s); break;

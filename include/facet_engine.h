@@ -96,6 +96,8 @@ int fe_op_bilinear(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int 
 int fe_op_adaptive_avgpool(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int ho, int wo, float* y);
 int fe_op_layernorm(fe_ctx* ctx, const float* x, int rows, int d, const float* g, const float* b, float eps, float* y);
 
+/* developer hook: force a tile variant of the contraction kernel for every later launch (0 = automatic choice) */
+int fe_set_conv_variant(fe_ctx* ctx, int variant);
 /* developer hook: average ms of one conv shape on random device-resident data with a forced tile variant (0 = auto) */
 int fe_bench_conv(fe_ctx* ctx, int n, int h, int w, int cin, int cout, int k, int stride, int pad, int with_res, int act,
                   int variant, int iters, float* ms_out);

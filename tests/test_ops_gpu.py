@@ -107,3 +107,23 @@ def test_layernorm(engine):
     w = torch.rand(1024, generator=g) + 0.5
     b = torch.randn(1024, generator=g)
     _close(engine.layernorm(x.numpy(), w.numpy(), b.numpy(), 1e-5), F.layer_norm(x, (1024,), w, b, 1e-5).numpy(), 1e-5)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 4, 7, 11, 12, 13, 14, 17, 18])
+def test_conv_tile_variants_agree(engine, variant):
+    """Every tile variant of the contraction kernel (register-staged, LDS-DMA, loader-wave) gives the same answer,
+    including ragged M/N edges, padding taps, stride 2 and a K that needs the zero-padded tail slab."""
+    g = torch.Generator().manual_seed(77)
+    cases = [(2, 48, 19, 23, 80, 3, 1, 1), (1, 64, 30, 30, 200, 1, 1, 0), (1, 32, 33, 31, 64, 3, 2, 1),
+             (3, 16, 9, 9, 40, 3, 1, 1)]
+    try:
+        for n, cin, h, w, cout, k, s, p in cases:
+            x = torch.randn(n, cin, h, w, generator=g)
+            wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+            res = torch.randn(n, cout, (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1, generator=g)
+            ref = F.relu(F.conv2d(x, wt, None, s, p) + res)
+            engine.set_conv_variant(variant)
+            got = engine.conv2d(x.numpy(), wt.numpy(), res=res.numpy(), stride=s, pad=p, act="relu")
+            _close(got, ref.numpy())
+    finally:
+        engine.set_conv_variant(0)
