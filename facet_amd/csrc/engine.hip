@@ -307,7 +307,22 @@ static void raw_gemm(Ctx& c, ConvParams& p, double flops) {
   p.Kp = (p.K + CONV_KALIGN - 1) / CONV_KALIGN * CONV_KALIGN;
   p.Cin = p.K;
   FE_CHECK(p.xs1 % 4 == 0 && p.xs2 % 4 == 0 && p.ws1 % 4 == 0 && p.ws2 % 4 == 0, "raw_gemm: batch strides must keep 16-B alignment");
-  launch_conv(p, c.stream);
+  if (c.profile) {
+    hipEvent_t e0, e1;
+    FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
+    FE_HIP(hipEventRecord(e0, c.stream));
+    launch_conv(p, c.stream);
+    FE_HIP(hipEventRecord(e1, c.stream));
+    FE_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FE_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    char nm[128];
+    snprintf(nm, sizeof nm, "bgemm x%d M=%d K=%d N=%d", p.batch > 1 ? p.batch : 1, p.M, p.K, p.Cout);
+    c.timings.push_back({nm, flops, 0.0, ms});
+  } else {
+    launch_conv(p, c.stream);
+  }
   c.flops_accum += flops;
 }
 

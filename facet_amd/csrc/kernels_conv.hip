@@ -321,11 +321,25 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
   const unsigned long long xspan = ((unsigned long long)p.N * p.H * p.W - 1) * (unsigned long long)p.ldx * 4 + (unsigned long long)p.Cin * 4;
   const unsigned long long wspan = ((unsigned long long)p.Cout - 1) * (unsigned long long)q.ldw * 4 + (unsigned long long)p.Kp * 4;
   if (!no_dma && p.Cin % 16 == 0 && p.KH * p.KW < 64 && xspan < 0xFFFFFF00ull && wspan < 0xFFFFFF00ull) {
-    const long long wg = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * q.batch;
-    int tile;
-    if (p.Cout > 64) tile = wg < 384 ? 4 : (p.K <= 256 ? 7 : 1);   // short-K layers are bandwidth-bound: favour occupancy
-    else if (p.Cout > 32) tile = wg < 192 ? 4 : 7;   // 128x64: 4 waves/SIMD beats 256x64 on every N<=64 layer measured
-    else tile = 3;
+    // Tile choice = wave-quantisation model: workgroups are dealt round-robin over the 256 CUs and the ones resident on
+    // a CU share its matrix pipes, so a launch lasts ~ ceil(WGs / 256) tiles per CU x (tile area / tile efficiency).
+    // Measured relative efficiencies on the ResNet/ViT shapes (tools/conv_bench.py): 128x128 1.00, 128x64 0.97, 64x64 0.93;
+    // short-K (bandwidth-bound) layers run best on the 128x64 tile (4 waves/SIMD).
+    struct Cand { int tile, bm, bn; double eff; };
+    static const Cand wide[3] = {{1, 128, 128, 1.00}, {7, 128, 64, 0.97}, {4, 64, 64, 0.93}};
+    static const Cand narrow[2] = {{7, 128, 64, 1.00}, {4, 64, 64, 0.95}};
+    int tile = 3;
+    if (p.Cout > 32) {
+      const Cand* cs = p.Cout > 64 ? wide : narrow;
+      const int nc = p.Cout > 64 ? 3 : 2;
+      double best = 1e300;
+      for (int i = 0; i < nc; ++i) {
+        if (p.Cout > 64 && p.K <= 256 && cs[i].tile == 1) continue;
+        const long long wgs = (long long)((p.M + cs[i].bm - 1) / cs[i].bm) * ((p.Cout + cs[i].bn - 1) / cs[i].bn) * q.batch;
+        const double cost = (double)((wgs + 255) / 256) * cs[i].bm * cs[i].bn / cs[i].eff;
+        if (cost < best) { best = cost; tile = cs[i].tile; }
+      }
+    }
     launch_conv_dma(q, tile, s);
     return;
   }

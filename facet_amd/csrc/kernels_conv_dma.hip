@@ -27,8 +27,10 @@ __device__ __forceinline__ float apply_act_d(float v, int act) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int WGM, int WGN, int TM, int TN>
-__global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4))) void conv_dma_kernel(ConvParams p, const int ntiles) {
+// MODE 0: 3-slab ring + double-buffered fragments (3 waves/SIMD for 64x64 wave tiles).
+// MODE 1: lean - 2 slabs, one fragment set, register budget of 128 so FOUR waves/SIMD are resident.
+template <int WGM, int WGN, int TM, int TN, int MODE = 0>
+__global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4)))) void conv_dma_kernel(ConvParams p, const int ntiles) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = 16;
   constexpr int AI = (BM + 63) / 64, BI = (BN + 63) / 64;   // DMA pieces per wave per slab (16 rows x 64 B each)
   constexpr int SLAB = (BM + BN) * BK;                      // floats per buffer
@@ -203,17 +205,32 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4))) v
     __builtin_amdgcn_sched_barrier(0);                                                                             \
   }
 
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
-  if (nk > 2) issue(2, 2);
-  wait_vm(nk > 2 ? 2 * npw : (nk > 1 ? npw : 0));
-  __builtin_amdgcn_s_barrier();
-  FE_READ_FRAGS(0, 0)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  for (int kt = 0; kt < nk; kt += 2) {
-    FE_STEP(0, 1, kt)
-    if (kt + 1 < nk) FE_STEP(1, 0, kt + 1)
+  if constexpr (MODE == 1) {
+    issue(0, 0);
+    wait_vm(0);
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      FE_READ_FRAGS(0, kt & 1)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      FE_MFMA_BURST(0)
+      wait_vm(0);
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    wait_vm(nk > 2 ? 2 * npw : (nk > 1 ? npw : 0));
+    __builtin_amdgcn_s_barrier();
+    FE_READ_FRAGS(0, 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < nk; kt += 2) {
+      FE_STEP(0, 1, kt)
+      if (kt + 1 < nk) FE_STEP(1, 0, kt + 1)
+    }
   }
 #undef FE_STEP
 #undef FE_MFMA_BURST
@@ -288,14 +305,14 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4))) v
   }
 }
 
-template <int WGM, int WGN, int TM, int TN>
+template <int WGM, int WGN, int TM, int TN, int MODE = 0>
 static void launch_dma_variant(const ConvParams& p, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
-  constexpr size_t main_lds = (size_t)3 * (BM + BN) * 16 * sizeof(float);
+  constexpr size_t main_lds = (size_t)(MODE == 1 ? 2 : 3) * (BM + BN) * 16 * sizeof(float);
   constexpr size_t epi_lds = (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
-  auto kern = conv_dma_kernel<WGM, WGN, TM, TN>;
+  auto kern = conv_dma_kernel<WGM, WGN, TM, TN, MODE>;
   static bool attr_set = false;
   if (!attr_set) {
     FE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -317,6 +334,8 @@ void launch_conv_dma(const ConvParams& p0, int tile, hipStream_t s) {
   p.x_span = (unsigned)xs; p.w_span = (unsigned)ws;
   switch (tile) {
     case 1: launch_dma_variant<2, 2, 2, 2>(p, s); break;
+    case 21: launch_dma_variant<2, 2, 2, 2, 1>(p, s); break;   // lean 128x128, 4 waves/SIMD
+    case 22: launch_dma_variant<4, 1, 2, 2, 1>(p, s); break;   // lean 256x64
     case 2: launch_dma_variant<4, 1, 2, 2>(p, s); break;
     case 3: launch_dma_variant<4, 1, 2, 1>(p, s); break;
     case 4: launch_dma_variant<2, 2, 1, 1>(p, s); break;

@@ -109,7 +109,7 @@ def test_layernorm(engine):
     _close(engine.layernorm(x.numpy(), w.numpy(), b.numpy(), 1e-5), F.layer_norm(x, (1024,), w, b, 1e-5).numpy(), 1e-5)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 7, 11, 12, 13, 14, 17, 18])
+@pytest.mark.parametrize("variant", [1, 2, 4, 7, 11, 12, 13, 14, 17, 18, 21, 22])
 def test_conv_tile_variants_agree(engine, variant):
     """Every tile variant of the contraction kernel (register-staged, LDS-DMA, loader-wave) gives the same answer,
     including ragged M/N edges, padding taps, stride 2 and a K that needs the zero-padded tail slab."""
