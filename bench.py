@@ -153,7 +153,7 @@ def main():
                        "weights": "seeded synthetic checkpoint (no weight files offline)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM, all launches of the step)",
+                         "kernel": "conv_dma_kernel + conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; every contraction launched in the timed region)",
                          "flops_per_image": round(flops / (B * args.steps), 1),
                          "event_ms": round(ev_ms, 3)},
         }
