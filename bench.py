@@ -72,10 +72,17 @@ def main():
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    # Rehearsal knobs (not used by the driver): FACET_BENCH_BACKEND=gloo + FACET_BENCH_DEVICE=0 let two ranks share one
+    # GPU so the N>1 control flow can be exercised on a 1-GPU box; the real multi-GPU run is nccl (= RCCL over xGMI).
+    backend = os.environ.get("FACET_BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("FACET_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from facet_amd import Engine
     from facet_amd._lib import (FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_AESTHETIC, FE_MODEL_SAMP, FE_MODEL_U2NETP)
@@ -83,7 +90,7 @@ def main():
     from facet_amd.sharding import shard_range, gather_scores
 
     B, HW = args.batch, args.size
-    eng = Engine(local_rank, arena_bytes=(4 + 2 * args.microbatch * max(1, (HW * HW) // (1024 * 1024))) << 30)
+    eng = Engine(dev_index, arena_bytes=(4 + 2 * args.microbatch * max(1, (HW * HW) // (1024 * 1024))) << 30)
     eng.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", seed=3))
     if args.workload == "ensemble":
         eng.load_weights(FE_MODEL_CLIP, synthetic_state_dict("clip", seed=3))
@@ -113,9 +120,9 @@ def main():
         if args.workload == "ensemble":
             rec, mask = eng.ensemble_score(images)      # [B, 789] per-image records
             assert mask == 7
-            return gather_scores(rec, world, local_rank)
+            return gather_scores(rec, world, dev_index)
         scores = eng.topiq_score(images)
-        return gather_scores(scores, world, local_rank)
+        return gather_scores(scores, world, dev_index)
 
     for _ in range(args.warmup):
         step()
@@ -131,7 +138,7 @@ def main():
     flops = eng.flops()
     assert allscores.shape[0] == B * world and np.isfinite(allscores).all()
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
