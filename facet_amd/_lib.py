@@ -75,6 +75,7 @@ SIGNATURES = {
     "fe_clip_encode_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
     "fe_samp_score_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
                                        _f32p, _f32p]),
+    "fe_tag_similarities": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, C.c_int, _f32p]),
     "fe_ensemble_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
                                     C.POINTER(C.c_int)]),
     "fe_u2netp_saliency": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
@@ -388,3 +389,13 @@ class Engine:
         mask = C.c_int(0)
         self._ck(self.lib.fe_ensemble_score(self.h, p, n, h, w, dev, rec.ctypes.data_as(_f32p), C.byref(mask)))
         return rec, mask.value
+
+    def tag_similarities(self, emb, text):
+        """emb [n,d], text [T,d] (L2-normalised rows) -> cosine similarities [n,T] computed on the GPU."""
+        emb, ep = _f32(emb)
+        text, tp = _f32(text)
+        n, d = emb.shape
+        T = text.shape[0]
+        out = np.empty((n, T), np.float32)
+        self._ck(self.lib.fe_tag_similarities(self.h, ep, n, tp, T, d, out.ctypes.data_as(_f32p)))
+        return out

@@ -642,6 +642,25 @@ int fe_samp_score_images(fe_ctx* ctx, const uint8_t* img, int n, int h, int w, i
   FE_API_END(ctx)
 }
 
+// Batched zero-shot tag scoring: sims[n][T] = emb[n][d] . text[T][d]^T on the matrix cores (both host, row-major).
+// Replaces the per-image `image_features @ text_embeddings.T` + python loop of models/tagger.py:100-106.
+int fe_tag_similarities(fe_ctx* ctx, const float* emb, int n, const float* text, int T, int d, float* sims) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(emb && text && sims && n > 0 && T > 0 && d > 0 && d % 4 == 0, "bad arguments");
+  C.arena.reset();
+  DeviceWeights dw;
+  HostTensor w; w.shape = {T, d}; w.data.assign(text, text + (size_t)T * d);
+  ConvW tw = build_linear_rows(dw, w, nullptr, 0, T);
+  float* d_e = (float*)C.arena.alloc((size_t)n * tw.CinPad * sizeof(float));
+  float* d_s = (float*)C.arena.alloc((size_t)n * T * sizeof(float));
+  FE_HIP(hipMemcpyAsync(d_e, emb, (size_t)n * d * sizeof(float), hipMemcpyHostToDevice, C.stream));
+  linear_forward(C, tw, d_e, d, n, d_s, T, ACT_NONE);
+  FE_HIP(hipMemcpyAsync(sims, d_s, (size_t)n * T * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
 // One call per batch for the whole ensemble (what processing/batch_processor.py:169-360 sequences per image):
 // record[i] = [topiq_raw, aesthetic_raw, pattern_weights(8), attributes(6), score_dist(5), clip_emb_norm(768)] = 789 floats.
 // Models that are not loaded leave their fields at 0 (mask bit i of *models_run: 1 topiq, 2 clip, 4 samp).

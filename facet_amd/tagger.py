@@ -53,6 +53,24 @@ class CLIPTagger:
         kept.sort(key=lambda x: x[1], reverse=True)
         return [t for t, _ in kept[:max_tags]]
 
+    def get_tags_batch(self, embeddings, engine, threshold=0.25, max_tags=5):
+        """Batched form of get_tags_from_embedding: one GPU GEMM for all images ([n,768] array or list of blobs),
+        then the reference's per-tag max / threshold / sort / top-k on the host."""
+        if self.text_embeddings is None:
+            return [[] for _ in embeddings]
+        embs = np.stack([bytes_to_embedding(e) if isinstance(e, (bytes, bytearray)) else np.asarray(e, np.float32)
+                         for e in embeddings]).astype(np.float32)
+        sims = engine.tag_similarities(embs, self.text_embeddings)
+        out = []
+        for row in sims:
+            scores = {}
+            for name, s in zip(self.tag_names, row):
+                if name not in scores or s > scores[name]:
+                    scores[name] = float(s)
+            kept = sorted(((t, s) for t, s in scores.items() if s >= threshold), key=lambda x: x[1], reverse=True)
+            out.append([t for t, _ in kept[:max_tags]])
+        return out
+
     def get_tags_with_scores(self, clip_embedding_bytes, threshold=0.20):
         if self.text_embeddings is None or clip_embedding_bytes is None:
             return {}

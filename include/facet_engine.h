@@ -145,6 +145,10 @@ int fe_clip_encode_images(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, 
  * Resize((224,224)), ToTensor, ImageNet Normalize, U2NETP saliency, SAMPNet. Outputs as fe_samp_forward. */
 int fe_samp_score_images(fe_ctx* ctx, const uint8_t* img, int n, int h, int w, int bgr, int on_device,
                          float* pattern_weights, float* attributes, float* score_dist);
+/* Batched tag scoring: sims[n][T] = emb[n][d] . text[T][d]^T. Replaces the per-image matmul + loop of
+ * CLIPTagger.get_tags_from_embedding (models/tagger.py:100-106); selection (max over synonyms, threshold, top-k) stays on host. */
+int fe_tag_similarities(fe_ctx* ctx, const float* emb, int n, const float* text, int T, int d, float* sims);
+
 /* The whole ensemble on one resident batch — what processing/batch_processor.py:169-360 sequences per image.
  * records [n][FE_RECORD_FLOATS]: [0] topiq raw MOS, [1] aesthetic raw, [2..9] SAMP pattern logits, [10..15] SAMP
  * attributes, [16..20] SAMP score distribution, [21..788] L2-normalised CLIP embedding. Fields of models that are

@@ -51,3 +51,25 @@ def test_model_manager_lifecycle_and_scorers(engine):
     assert abs(again.score_image(pils[1]) - s[1]) < 1e-4
     mm.unload_all(); mm.evict_cpu_cache()
     assert mm.get_loaded_models() == []
+
+
+def test_batched_tag_scoring_matches_per_image_path(engine):
+    from facet_amd.tagger import CLIPTagger
+
+    class Cfg:
+        def get_tag_vocabulary(self):
+            return {f"tag{i}": [f"t{i}a", f"t{i}b"] for i in range(37)}
+
+        def get_art_tags(self):
+            return set()
+    tg = CLIPTagger(None, "cuda", Cfg())
+    rng = np.random.default_rng(3)
+    names, _ = tg.prompts()
+    tg.set_text_embeddings(names, rng.standard_normal((len(names), 768)))
+    embs = rng.standard_normal((9, 768)).astype(np.float32)
+    embs /= np.linalg.norm(embs, axis=1, keepdims=True)
+    sims = engine.tag_similarities(embs, tg.text_embeddings)
+    assert np.abs(sims - embs @ tg.text_embeddings.T).max() < 1e-5
+    batched = tg.get_tags_batch([e.tobytes() for e in embs], engine, threshold=0.02, max_tags=5)
+    single = [tg.get_tags_from_embedding(e.tobytes(), threshold=0.02, max_tags=5) for e in embs]
+    assert batched == single
