@@ -1,6 +1,7 @@
 // Engine runtime: weight packing, conv/linear wrappers and the ResNet graphs.
 #include "engine.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace fe {
 
@@ -334,7 +335,9 @@ void mha_forward(Ctx& c, const MHAW& m, const float* q_in, int ldq, const float*
   float* Q = (float*)c.arena.alloc((size_t)B * Lq * d * sizeof(float));
   float* K = (float*)c.arena.alloc((size_t)B * Lk * d * sizeof(float));
   float* Vt = (float*)c.arena.alloc((size_t)B * d * Lp * sizeof(float));
-  float* S = (float*)c.arena.alloc((size_t)B * H * Lq * Lp * sizeof(float));
+  static const bool no_flash = getenv("FE_NO_FLASH") != nullptr;
+  const bool flash = (hd == 64) && !no_flash;
+  float* S = flash ? nullptr : (float*)c.arena.alloc((size_t)B * H * Lq * Lp * sizeof(float));
   float* O = (float*)c.arena.alloc((size_t)B * Lq * d * sizeof(float));
   linear_forward(c, m.q, q_in, ldq, B * Lq, Q, d, ACT_NONE);
   linear_forward(c, m.k, kv_in, ldkv, B * Lk, K, d, ACT_NONE);
@@ -346,26 +349,32 @@ void mha_forward(Ctx& c, const MHAW& m, const float* q_in, int ldq, const float*
     p.batch = B; p.nb1 = 1; p.ws2 = (long long)Lk * ldkv; p.ys2 = (long long)d * Lp;
     raw_gemm(c, p, 2.0 * B * d * (double)d * Lk);
   }
+  if (flash) {
+    // fused QK^T -> online softmax -> PV (kernels_attn.hip); scores never touch HBM
+    launch_attention(Q, d, K, d, Vt, Lp, m.bv, O, d, B, H, Lq, Lk, d, c.stream);
+    c.flops_accum += 4.0 * B * H * (double)Lq * Lk * hd;
+  } else {
   {  // S[b,h] [Lq][Lk] = Q_bh K_bh^T
-    ConvParams p{};
-    p.x = Q; p.ldx = d; p.w = K; p.ldw = d; p.y = S; p.ldy = Lp;
-    p.M = Lq; p.K = hd; p.Cout = Lk;
-    p.batch = B * H; p.nb1 = H;
-    p.xs1 = hd; p.xs2 = (long long)Lq * d; p.ws1 = hd; p.ws2 = (long long)Lk * d;
-    p.ys1 = (long long)Lq * Lp; p.ys2 = (long long)H * Lq * Lp;
-    raw_gemm(c, p, 2.0 * B * H * (double)Lq * Lk * hd);
-  }
-  launch_softmax_rows_pad(S, Lp, B * H * Lq, Lk, c.stream);
-  {  // O[b][:, h*hd:(h+1)*hd] = P_bh V_bh + bv_h
-    ConvParams p{};
-    p.x = S; p.ldx = Lp; p.w = Vt; p.ldw = Lp; p.y = O; p.ldy = d;
-    p.shift = m.bv; p.hs1 = hd;
-    p.M = Lq; p.K = Lp; p.Cout = hd;
-    p.batch = B * H; p.nb1 = H;
-    p.xs1 = (long long)Lq * Lp; p.xs2 = (long long)H * Lq * Lp;
-    p.ws1 = (long long)hd * Lp; p.ws2 = (long long)d * Lp;
-    p.ys1 = hd; p.ys2 = (long long)Lq * d;
-    raw_gemm(c, p, 2.0 * B * H * (double)Lq * Lk * hd);
+      ConvParams p{};
+      p.x = Q; p.ldx = d; p.w = K; p.ldw = d; p.y = S; p.ldy = Lp;
+      p.M = Lq; p.K = hd; p.Cout = Lk;
+      p.batch = B * H; p.nb1 = H;
+      p.xs1 = hd; p.xs2 = (long long)Lq * d; p.ws1 = hd; p.ws2 = (long long)Lk * d;
+      p.ys1 = (long long)Lq * Lp; p.ys2 = (long long)H * Lq * Lp;
+      raw_gemm(c, p, 2.0 * B * H * (double)Lq * Lk * hd);
+    }
+    launch_softmax_rows_pad(S, Lp, B * H * Lq, Lk, c.stream);
+    {  // O[b][:, h*hd:(h+1)*hd] = P_bh V_bh + bv_h
+      ConvParams p{};
+      p.x = S; p.ldx = Lp; p.w = Vt; p.ldw = Lp; p.y = O; p.ldy = d;
+      p.shift = m.bv; p.hs1 = hd;
+      p.M = Lq; p.K = Lp; p.Cout = hd;
+      p.batch = B * H; p.nb1 = H;
+      p.xs1 = (long long)Lq * Lp; p.xs2 = (long long)H * Lq * Lp;
+      p.ws1 = (long long)hd * Lp; p.ws2 = (long long)d * Lp;
+      p.ys1 = hd; p.ys2 = (long long)Lq * d;
+      raw_gemm(c, p, 2.0 * B * H * (double)Lq * Lk * hd);
+    }
   }
   linear_forward(c, m.out, O, d, B * Lq, y, ldy, ACT_NONE, res, ldr);
   c.arena.rewind(mark);

@@ -171,6 +171,9 @@ void launch_adaptive_avgpool(const Tensor& x, const Tensor& y, hipStream_t s);
 void launch_tap_gather(const float* z, int ldz, int n, int h, int w, int kh, int kw, int ph, int pw, int dh, int dw,
                        int cout, const float* scale, const float* shift, int act, float* y, int ldy, int ho, int wo,
                        hipStream_t s);
+// fused attention, head_dim 64 (kernels_attn.hip): o = softmax(q k^T) v + bv per (batch, head)
+void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* vt, int lp, const float* bv, float* o,
+                      int ldo, int B, int H, int Lq, int Lk, int dmodel, hipStream_t s);
 void launch_sigmoid(const Tensor& x, const Tensor& y, hipStream_t s);
 void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s);
 // LayerNorm over last dim of a [rows][d] matrix (eps inside sqrt, biased variance)
