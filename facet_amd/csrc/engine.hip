@@ -50,12 +50,18 @@ static ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector
   c.K = c.KH * c.KW * c.CinPad;
   c.Kp = (c.K + CONV_KALIGN - 1) / CONV_KALIGN * CONV_KALIGN;
   std::vector<float> packed((size_t)c.Cout * c.Kp, 0.f);
+  // K order: (tap, ci) for the generic kernel; for CinPad % 16 == 0 (the fast kernels) 16-channel block outer, tap
+  // inner, ci-in-block innermost, so consecutive K slabs are the taps of one channel block.
+  const bool blocked = (c.CinPad % 16 == 0);
+  const int ntaps = c.KH * c.KW;
   for (int co = 0; co < c.Cout; ++co)
     for (int ci = 0; ci < c.Cin; ++ci)
       for (int kh = 0; kh < c.KH; ++kh)
-        for (int kw = 0; kw < c.KW; ++kw)
-          packed[(size_t)co * c.Kp + (size_t)(kh * c.KW + kw) * c.CinPad + ci] =
-              w.data[(((size_t)co * c.Cin + ci) * c.KH + kh) * c.KW + kw];
+        for (int kw = 0; kw < c.KW; ++kw) {
+          const int tap = kh * c.KW + kw;
+          const size_t k = blocked ? ((size_t)(ci / 16) * ntaps + tap) * 16 + (ci % 16) : (size_t)tap * c.CinPad + ci;
+          packed[(size_t)co * c.Kp + k] = w.data[(((size_t)co * c.Cin + ci) * c.KH + kh) * c.KW + kw];
+        }
   c.w = dw.upload(packed);
   if (c.Cout <= 2 && c.KH * c.KW > 1 && c.CinPad % 16 == 0) {
     // tap-decomposed form: z[pixel][tap*Cout+co] = <x[pixel], w[co][tap]> as a 1x1 conv, neighbours summed afterwards

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, const int
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const int ih = ih0[i] + kh * p.dh, iw = iw0[i] + kw * p.dw;
-      const bool ok = mval[i] && (kh < p.KH) && ((unsigned)ih < (unsigned)p.H) &&
+      const bool ok = mval[i] && (kh < p.KH) && (!FAST || ci < p.Cin) && ((unsigned)ih < (unsigned)p.H) &&
                       ((unsigned)iw < (unsigned)p.W);
       if (ok) {
         const float* src = p.x + (abase[i] + (size_t)ih * p.W + iw) * p.ldx + cofs;
@@ -124,10 +124,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, const int
       else rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // advance k state to the next slab
-    ci += BK;
-    while (ci >= p.Cin) {
-      ci -= p.Cin;
+    if (FAST) {
+      // packed K order for Cin % 16 == 0: 16-channel block outer, tap inner (see pack_conv / kernels_conv_dma.hip)
       if (++kw == p.KW) { kw = 0; ++kh; }
+      if (kh == p.KH) { kh = 0; kw = 0; ci += 16; }
+    } else {
+      ci += BK;
+      while (ci >= p.Cin) {
+        ci -= p.Cin;
+        if (++kw == p.KW) { kw = 0; ++kh; }
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -284,7 +290,6 @@ static void launch_forced(const ConvParams& q, hipStream_t s) {
     case 2: launch_variant<4, 1, 2, 2, 16, true>(q, s); break;   // 256x64
     case 3: launch_variant<4, 1, 2, 1, 16, true>(q, s); break;   // 256x32
     case 4: launch_variant<2, 2, 1, 1, 16, true>(q, s); break;   // 64x64
-    case 5: launch_variant<2, 2, 2, 2, 32, true>(q, s); break;   // 128x128 BK32
     case 6: launch_variant<1, 4, 2, 2, 16, true>(q, s); break;   // 64x256
     case 7: launch_variant<2, 2, 2, 1, 16, true>(q, s); break;   // 128x64
     default: FE_CHECK(false, "unknown conv variant %d", q.variant);
@@ -310,8 +315,6 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
               (!p.gate || p.gate_c1 || (p.ldg % 4 == 0 && al16(p.gate))) && (!p.scale || al16(p.scale)) &&
               (!p.shift || (al16(p.shift) && p.hs1 % 4 == 0)) && (p.batch <= 1 || (p.ys1 % 4 == 0 && p.ys2 % 4 == 0));
   const bool fast = (p.Cin % 16 == 0);
-  static const bool bk32 = getenv("FE_BK32") != nullptr;   // experiment switch (tools/perf_topiq.py)
-  const bool f32 = bk32 && (p.Cin % 32 == 0);
   // Tile choice: 128x128 for wide outputs, 256x64 / 256x32 for narrow ones; problems too small to give every
   // CU a 128x128 tile drop to 64x64 tiles (4x the workgroups).
   if (q.variant % 100 > 10 && q.variant % 100 < 40) { q.dbg = q.variant / 100; launch_conv_dma(q, (q.variant % 100 > 20) ? q.variant % 100 : q.variant % 100 - 10, s); return; }
@@ -346,12 +349,10 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
   const long long wg128 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * q.batch;
   if (p.Cout > 64) {
     if (wg128 < 384 && fast) launch_variant<2, 2, 1, 1, 16, true>(q, s);
-    else if (f32) launch_variant<2, 2, 2, 2, 32, true>(q, s);
     else if (fast) launch_variant<2, 2, 2, 2, 16, true>(q, s);
     else launch_variant<2, 2, 2, 2, 16, false>(q, s);
   } else if (p.Cout > 32) {
     if (wg128 < 192 && fast) launch_variant<2, 2, 1, 1, 16, true>(q, s);
-    else if (f32) launch_variant<4, 1, 2, 2, 32, true>(q, s);
     else if (fast) launch_variant<4, 1, 2, 2, 16, true>(q, s);
     else launch_variant<4, 1, 2, 2, 16, false>(q, s);
   } else {

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
 #pragma unroll
       for (int j = 0; j < AI; ++j) {
         if (16 * (4 * j + wave) < BM) {
-          const bool ok = (amask[j] >> tap) & 1ull;
+          const bool ok = ((amask[j] >> tap) & 1ull) && (ci < p.Cin);   // ci == Cin only in the zero-padded K tail
           const unsigned off = ok ? aoffs[j] + (unsigned)tb : 0xFFFFFFF0u;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(Ab + 256 * (4 * j + wave)), 16, (int)off, 0, 0, 0);
         }
@@ -120,11 +120,11 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
         if (16 * (4 * j + wave) < BN)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(Bb + 256 * (4 * j + wave)), 16, (int)boffs[j], tbb2, 0, 0);
       }
-      ci += BK;
-      if (ci >= p.Cin) {
-        ci = 0; ++tap;
-        if (++kw == p.KW) { kw = 0; ++kh; }
-      }
+      // K order: 16-channel block outer, tap inner - the 9 taps of a 3x3 re-read the same input rows back to back,
+      // so the re-reads hit L1/L2 instead of coming back from the Infinity Cache a third of a K-loop later.
+      ++tap;
+      if (++kw == p.KW) { kw = 0; ++kh; }
+      if (tap == ntaps) { tap = 0; kh = 0; kw = 0; ci += BK; }
     }
   };
 
