@@ -29,7 +29,7 @@ struct AttnParams {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * ATT_KS];
   __shared__ __attribute__((aligned(16))) float Vs[2][64 * ATT_VS];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -49,34 +49,38 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
   // staging coordinates: K tile = 32 rows x 16 chunks (512 chunks), V^T tile = 64 rows x 8 chunks (512 chunks)
   constexpr int NT = NW * 64;
   constexpr int KP = 512 / NT, VP = 512 / NT;
-  float4 kreg[KP], vreg[VP];
-  auto load_tile = [&](int kt) {
-    const int k0 = kt * 32;
-#pragma unroll
-    for (int i = 0; i < KP; ++i) {
-      const int c = t + i * NT;
-      int row = k0 + (c >> 4);
-      if (row > p.Lk - 1) row = p.Lk - 1;          // masked after the QK^T product
-      kreg[i] = *reinterpret_cast<const float4*>(Kp + (size_t)row * p.ldk + (c & 15) * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < VP; ++i) {
-      const int c = t + i * NT;
-      vreg[i] = *reinterpret_cast<const float4*>(Vp + (size_t)(c >> 3) * p.lp + k0 + (c & 7) * 4);   // pad columns are zero
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < KP; ++i) {
-      const int c = t + i * NT;
-      *reinterpret_cast<float4*>(&Ks[buf][(c >> 4) * ATT_KS + (c & 15) * 4]) = kreg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < VP; ++i) {
-      const int c = t + i * NT;
-      *reinterpret_cast<float4*>(&Vs[buf][(c >> 3) * ATT_VS + (c & 7) * 4]) = vreg[i];
-    }
-  };
+  // Prefetch registers are named scalars on purpose: as arrays (even with fully unrolled static indices) hipcc kept
+  // them in scratch memory, which showed up as 88 MB/image of WRITE_SIZE in the profile.
+  float4 kr0, kr1, kr2 = {}, kr3 = {}, vr0, vr1, vr2 = {}, vr3 = {};
+#define ATT_LD_K(REG, I)                                                                                  \
+  {                                                                                                       \
+    const int c = t + (I) * NT;                                                                           \
+    int row = k0_ + (c >> 4);                                                                             \
+    if (row > p.Lk - 1) row = p.Lk - 1; /* masked after the QK^T product */                              \
+    REG = *reinterpret_cast<const float4*>(Kp + (size_t)row * p.ldk + (c & 15) * 4);                      \
+  }
+#define ATT_LD_V(REG, I)                                                                                  \
+  {                                                                                                       \
+    const int c = t + (I) * NT;                                                                           \
+    REG = *reinterpret_cast<const float4*>(Vp + (size_t)(c >> 3) * p.lp + k0_ + (c & 7) * 4); /* pad = 0 */ \
+  }
+#define ATT_LOAD_TILE(KT)                                    \
+  {                                                          \
+    const int k0_ = (KT) * 32;                               \
+    ATT_LD_K(kr0, 0) ATT_LD_K(kr1, 1)                        \
+    if (KP > 2) { ATT_LD_K(kr2, 2) ATT_LD_K(kr3, 3) }        \
+    ATT_LD_V(vr0, 0) ATT_LD_V(vr1, 1)                        \
+    if (VP > 2) { ATT_LD_V(vr2, 2) ATT_LD_V(vr3, 3) }        \
+  }
+#define ATT_ST_K(REG, I, BUF) { const int c = t + (I) * NT; *reinterpret_cast<float4*>(&Ks[BUF][(c >> 4) * ATT_KS + (c & 15) * 4]) = REG; }
+#define ATT_ST_V(REG, I, BUF) { const int c = t + (I) * NT; *reinterpret_cast<float4*>(&Vs[BUF][(c >> 3) * ATT_VS + (c & 7) * 4]) = REG; }
+#define ATT_STORE_TILE(BUF)                                          \
+  {                                                                  \
+    ATT_ST_K(kr0, 0, BUF) ATT_ST_K(kr1, 1, BUF)                      \
+    if (KP > 2) { ATT_ST_K(kr2, 2, BUF) ATT_ST_K(kr3, 3, BUF) }      \
+    ATT_ST_V(vr0, 0, BUF) ATT_ST_V(vr1, 1, BUF)                      \
+    if (VP > 2) { ATT_ST_V(vr2, 2, BUF) ATT_ST_V(vr3, 3, BUF) }      \
+  }
 
   f32x16 o0, o1;
 #pragma unroll
@@ -84,12 +88,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
   float m = -INFINITY, l = 0.f;
 
   const int nt = (p.Lk + 31) / 32;
-  load_tile(0);
-  store_tile(0);
+  ATT_LOAD_TILE(0)
+  ATT_STORE_TILE(0)
   __syncthreads();
   for (int kt = 0; kt < nt; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nt) load_tile(kt + 1);
+    if (kt + 1 < nt) ATT_LOAD_TILE(kt + 1)
     // ---- S^T = K Q^T -------------------------------------------------------------------------------------
     f32x16 st;
 #pragma unroll
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.w, st[4 * g + 3], o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.w, st[4 * g + 3], o1, 0, 0, 0);
     }
-    if (kt + 1 < nt) store_tile(buf ^ 1);
+    if (kt + 1 < nt) ATT_STORE_TILE(buf ^ 1)
     __syncthreads();
   }
   // ---- epilogue: O[q][head*64 + d] = O^T[d][q] / l + bv[d]; register e of tile dt is d = 32*dt + (e&3) + 8(e>>2) + 4h
