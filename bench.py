@@ -144,6 +144,15 @@ def main():
     dt_max = float(t.item())
 
     if rank == 0:
+        # HBM traffic of the same workload from the PMC passes (profiles/r01_traffic.json; collected with rocprofv3 --pmc
+        # FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this script, gfx950 correction: FETCH_SIZE counts 64 B per
+        # 128-B request, so it is doubled - /opt/skills/guides/MI355X_MICROARCH.md, HBM section). Bytes per STEP of one GPU.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath)).get(args.workload)
+            if tj and tj.get("image_size") == HW:
+                traffic = int((2.0 * tj["fetch_kb_per_image"] + tj["write_kb_per_image"]) * 1024 * B)
         total_images = B * world * args.steps
         achieved = flops / (ev_ms * 1e-3) / 1e12
         out = {
@@ -159,7 +168,8 @@ def main():
                        "parallelism": f"image-sharded x{world}, RCCL all-gather of scores",
                        "weights": "seeded synthetic checkpoint (no weight files offline)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per step per GPU (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
                          "kernel": "conv_dma_kernel + conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; every contraction launched in the timed region)",
                          "flops_per_image": round(flops / (B * args.steps), 1),
                          "event_ms": round(ev_ms, 3)},

@@ -24,9 +24,11 @@ struct fe_ctx {
 
 static std::string g_create_err;
 
+// every entry point re-selects the context's device: the calling thread may share the process with torch / RCCL
 #define FE_API_BEGIN(ctx)                         \
   if (!(ctx)) return FE_ERR_INVALID;              \
-  try {
+  try {                                           \
+    (void)hipSetDevice((ctx)->c.device);
 #define FE_API_END(ctx)                           \
   }                                               \
   catch (const std::exception& e) {               \
