@@ -278,6 +278,12 @@ namespace fe {
 
 void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act,
                     const float* res, int ldr) {
+  if (M <= 32 && !res && c.force_variant == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w.w) & 15) == 0) {
+    // per-image vectors: stream the weight matrix once instead of idling 255 CUs behind one 128-row tile
+    launch_gemm_skinny(x, ldx, w.w, w.Kp, w.scale, w.shift, y, ldy, M, w.Cout, w.K, act, c.stream);
+    c.flops_accum += 2.0 * M * (double)w.Cin * w.Cout;
+    return;
+  }
   Tensor xt = mat_view(x, M, w.CinPad, ldx), yt = mat_view(y, M, w.Cout, ldy);
   ConvOpts o; o.act = act;
   Tensor rt;

@@ -174,6 +174,9 @@ void launch_tap_gather(const float* z, int ldz, int n, int h, int w, int kh, int
 // fused attention, head_dim 64 (kernels_attn.hip): o = softmax(q k^T) v + bv per (batch, head)
 void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* vt, int lp, const float* bv, float* o,
                       int ldo, int B, int H, int Lq, int Lk, int dmodel, hipStream_t s);
+// M <= 32 rows: one wave per output column (kernels_misc.hip)
+void launch_gemm_skinny(const float* x, int ldx, const float* w, int ldw, const float* scale, const float* shift, float* y,
+                        int ldy, int M, int N, int K, int act, hipStream_t s);
 void launch_sigmoid(const Tensor& x, const Tensor& y, hipStream_t s);
 void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s);
 // LayerNorm over last dim of a [rows][d] matrix (eps inside sqrt, biased variance)

@@ -305,6 +305,61 @@ void launch_tap_gather(const float* z, int ldz, int n, int h, int w, int kh, int
   FE_HIP(hipGetLastError());
 }
 
+// ---- skinny GEMM (M <= 32 rows): y[m][n] = act(sum_k x[m][k] w[n][k] * scale[n] + shift[n]) -----------------------
+// One wave per output column streams its weight row once (16 B per lane); the <= 32 activation rows come from L1/L2.
+// Used for the per-image vectors of the heads (SAMP pattern "convs" K up to 7524, score MLPs, CLIP projection) where a
+// 128-row MFMA tile would leave 255 of 256 CUs idle behind a K loop thousands of steps long.
+template <int MR>
+__global__ void gemm_skinny_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw,
+                                   const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ y,
+                                   int ldy, int M, int N, int K, int act) {
+  const int lane = threadIdx.x & 63;
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (n >= N) return;
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  const float* wr = w + (size_t)n * ldw;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m < M) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + k);
+        acc[m] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    float v = acc[m];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    acc[m] = v;
+  }
+  if (lane == 0) {
+    const float sc = scale ? scale[n] : 1.f, sf = shift ? shift[n] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m < M) {
+        float v = acc[m] * sc + sf;
+        if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        else if (act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+        y[(size_t)m * ldy + n] = v;
+      }
+    }
+  }
+}
+void launch_gemm_skinny(const float* x, int ldx, const float* w, int ldw, const float* scale, const float* shift, float* y,
+                        int ldy, int M, int N, int K, int act, hipStream_t s) {
+  FE_CHECK(M >= 1 && M <= 32 && K % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0, "gemm_skinny: M=%d K=%d", M, K);
+  const int blocks = (N * 64 + 255) / 256;
+  if (M <= 8) hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3(blocks), dim3(256), 0, s, x, ldx, w, ldw, scale, shift, y, ldy, M, N, K, act);
+  else hipLaunchKernelGGL(gemm_skinny_kernel<32>, dim3(blocks), dim3(256), 0, s, x, ldx, w, ldw, scale, shift, y, ldy, M, N, K, act);
+  FE_HIP(hipGetLastError());
+}
+
 // ---- LayerNorm: one wave per row, two-pass (mean, then centred variance) in registers ------------------
 __global__ void layernorm_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                  const float* __restrict__ g, const float* __restrict__ b, int rows, int d, float eps) {
