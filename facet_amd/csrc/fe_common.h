@@ -119,7 +119,6 @@ struct ConvParams {
   int batch, nb1;
   long long xs1, xs2, ws1, ws2, ys1, ys2, hs1;   // hs1: shift stride per inner index
   int buf_ok; unsigned x_span, w_span;  // set by launch_conv_dma: operands addressable through 32-bit buffer offsets
-  int dbg;                          // timing experiments only (bit0 skip global loads, bit1 skip LDS stores, bit2 skip barrier)
   int variant;                      // 0 = auto tile choice; >0 forces a tile variant (tools/conv_bench.py)
 };
 

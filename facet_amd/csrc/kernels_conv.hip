@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, const int
   const int arow = wm * TM * 32 + r, brow = wn * TN * 32 + r;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk && !(p.dbg & 1)) load_tile(kt + 1);
+    if (kt + 1 < nk) load_tile(kt + 1);
     const float* Ab = As + (buf * BM + arow) * S + h * 4;
     const float* Bb = Bs + (buf * BN + brow) * S + h * 4;
 #pragma unroll
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, const int
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk && !(p.dbg & 2)) store_tile(buf ^ 1);
-    if (!(p.dbg & 4)) __syncthreads();
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
   }
 
   // ---- epilogue -----------------------------------------------------------------------------------
@@ -317,8 +317,9 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
   const bool fast = (p.Cin % 16 == 0);
   // Tile choice: 128x128 for wide outputs, 256x64 / 256x32 for narrow ones; problems too small to give every
   // CU a 128x128 tile drop to 64x64 tiles (4x the workgroups).
-  if (q.variant % 100 > 10 && q.variant % 100 < 40) { q.dbg = q.variant / 100; launch_conv_dma(q, (q.variant % 100 > 20) ? q.variant % 100 : q.variant % 100 - 10, s); return; }
-  if (q.variant > 0) { q.dbg = q.variant / 100; q.variant %= 100; launch_forced(q, s); return; }
+  // forced variants (tests / tools): 1-7 register-staged tiles, 11-18 LDS-DMA tiles, 21/22 lean LDS-DMA tiles
+  if (q.variant > 10 && q.variant < 40) { launch_conv_dma(q, q.variant > 20 ? q.variant : q.variant - 10, s); return; }
+  if (q.variant > 0) { launch_forced(q, s); return; }
   if (p.Cout <= 4 && q.batch <= 1 && !p.gate && q.variant == 0) { launch_conv_narrow(q, s); return; }
   static const bool no_dma = getenv("FE_NO_DMA") != nullptr;
   const unsigned long long xspan = ((unsigned long long)p.N * p.H * p.W - 1) * (unsigned long long)p.ldx * 4 + (unsigned long long)p.Cin * 4;
