@@ -382,8 +382,18 @@ static const float kImagenetMean[3] = {0.485f, 0.456f, 0.406f};
 static const float kImagenetStd[3] = {0.229f, 0.224f, 0.225f};
 
 // Runs the backbone on images [i0, i0+nb) of a device-resident u8 batch.
+// Long edge > 1024 is first reduced with PIL-exact LANCZOS to (int(w*s), int(h*s)), s = 1024/long_edge, exactly as
+// PyIQAScorer._preprocess_image does on the host (reference models/pyiqa_scorer.py:131-153).
 static void topiq_backbone_chunk(fe_ctx* ctx, const uint8_t* d_rgb, int nb, int h, int w, std::vector<Tensor>& feats) {
   Ctx& C = ctx->c;
+  const int long_edge = h > w ? h : w;
+  if (long_edge > 1024) {
+    const double sc = 1024.0 / long_edge;
+    const int nw = (int)(w * sc), nh = (int)(h * sc);
+    uint8_t* small = (uint8_t*)C.arena.alloc((size_t)nb * nh * nw * 3);
+    resize_u8(C, d_rgb, nb, h, w, nh, nw, FE_FILTER_LANCZOS, 0, nh, 0, nw, small);
+    d_rgb = small; h = nh; w = nw;
+  }
   Tensor x = C.arena.tensor(nb, h, w, 4);
   launch_u8_to_nhwc4_norm(d_rgb, x.p, (size_t)nb * h * w, kImagenetMean, kImagenetStd, 0, C.stream);
   resnet_forward(C, ctx->c.topiq->backbone, x, &feats);

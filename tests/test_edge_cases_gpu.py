@@ -76,3 +76,17 @@ def test_reload_cycles_do_not_leak_device_memory(engine):
         engine.unload(FE_MODEL_SAMP)
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < (64 << 20), f"leaked {(free0 - free1) >> 20} MiB over 4 load/unload cycles"
+
+
+def test_topiq_long_edge_cap_matches_reference_preprocessing(engine):
+    """Images with a long edge > 1024 are LANCZOS-reduced on the GPU exactly like PyIQAScorer._preprocess_image does with
+    PIL on the host (reference pyiqa_scorer.py:131-153): engine(raw big image) == engine(PIL-resized image)."""
+    from PIL import Image
+    engine.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", 3))
+    big = synthetic_images(31, 2, 700, 1400)
+    scale = 1024 / 1400
+    small = np.stack([np.asarray(Image.fromarray(a).resize((int(1400 * scale), int(700 * scale)), Image.LANCZOS)) for a in big])
+    engine.set_microbatch(2)
+    a = engine.topiq_score(big)
+    b = engine.topiq_score(small)
+    assert np.array_equal(a, b)
