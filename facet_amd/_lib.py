@@ -75,6 +75,7 @@ SIGNATURES = {
     "fe_clip_encode_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
     "fe_samp_score_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
                                        _f32p, _f32p]),
+    "fe_clip_encode_text": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int, _f32p]),
     "fe_tag_similarities": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, C.c_int, _f32p]),
     "fe_ensemble_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
                                     C.POINTER(C.c_int)]),
@@ -398,4 +399,12 @@ class Engine:
         T = text.shape[0]
         out = np.empty((n, T), np.float32)
         self._ck(self.lib.fe_tag_similarities(self.h, ep, n, tp, T, d, out.ctypes.data_as(_f32p)))
+        return out
+
+    def clip_encode_text(self, tokens, out_dim=768):
+        """tokens: int [n, 77] -> un-normalised text features [n, 768]."""
+        tk = np.ascontiguousarray(tokens, dtype=np.int32)
+        n, L = tk.shape
+        out = np.empty((n, out_dim), np.float32)
+        self._ck(self.lib.fe_clip_encode_text(self.h, tk.ctypes.data_as(C.POINTER(C.c_int32)), n, L, out.ctypes.data_as(_f32p)))
         return out

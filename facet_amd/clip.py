@@ -5,7 +5,8 @@
   m.encode_image(Tensor[B,3,224,224]) -> Tensor[B,768]
   next(m.parameters()).dtype               (callers test for float16, scorer.py:658; multi_pass.py:519)
   m.to()/.cpu()/.half()/.eval()
-The text tower (`encode_text`, tagger.py:73) is a SURVEY §8(f) "next" row and raises NotImplementedError.
+`m.encode_text(tokens)` (tagger.py:73) runs the text tower on the engine when the checkpoint carries it; the BPE
+tokenizer itself ships inside open_clip and is not re-implemented here (pass token ids).
 """
 import numpy as np
 
@@ -46,7 +47,12 @@ class CLIPImageModel:
         return torch.from_numpy(feat)
 
     def encode_text(self, tokens):
-        raise NotImplementedError("CLIP text tower is not part of the engine yet (SURVEY.md §8f-3)")
+        """tokens: int tensor/array [n,77] (open_clip tokenizer output) -> Tensor[n,768]; needs a full CLIP checkpoint
+        (token_embedding.weight etc.) to have been loaded."""
+        import torch
+        self._resident()
+        tk = tokens.detach().cpu().numpy() if hasattr(tokens, "detach") else np.asarray(tokens)
+        return torch.from_numpy(self._engine.clip_encode_text(tk))
 
     def parameters(self):
         import torch

@@ -198,6 +198,13 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
     auto m = std::make_unique<ClipModel>();
     build_clip(*m, ws);
     ctx->c.clip = std::move(m);
+    if (ws.has("token_embedding.weight")) {   // full CLIP checkpoint: also build the text tower
+      auto t = std::make_unique<ClipTextModel>();
+      build_clip_text(*t, ws);
+      ctx->c.clip_text = std::move(t);
+    } else {
+      ctx->c.clip_text.reset();
+    }
   } else if (model == FE_MODEL_AESTHETIC) {
     auto m = std::make_unique<AestheticModel>();
     build_aesthetic(*m, ws);
@@ -219,7 +226,7 @@ int fe_model_unload(fe_ctx* ctx, int model) {
   if (model == FE_MODEL_TOPIQ) ctx->c.topiq.reset();
   if (model == FE_MODEL_U2NETP) ctx->c.u2netp.reset();
   if (model == FE_MODEL_SAMP) ctx->c.samp.reset();
-  if (model == FE_MODEL_CLIP) ctx->c.clip.reset();
+  if (model == FE_MODEL_CLIP) { ctx->c.clip.reset(); ctx->c.clip_text.reset(); }
   if (model == FE_MODEL_AESTHETIC) ctx->c.aesthetic.reset();
   FE_API_END(ctx)
 }
@@ -650,6 +657,38 @@ int fe_samp_score_images(fe_ctx* ctx, const uint8_t* img, int n, int h, int w, i
   FE_HIP(hipMemcpyAsync(pattern_weights, d_out, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipMemcpyAsync(attributes, d_out + (size_t)n * 8, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipMemcpyAsync(score_dist, d_out + (size_t)n * 14, (size_t)n * 5 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+// CLIP text tower: tokens int32 [n][ctx_len] (host) -> un-normalised text features [n][768].
+// Reference: `self.model.encode_text(text_tokens)` in CLIPTagger._precompute_text_embeddings (models/tagger.py:69-75).
+int fe_clip_encode_text(fe_ctx* ctx, const int32_t* tokens, int n, int ctx_len, float* features) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  if (!C.clip_text) { C.err = "clip text tower not loaded (checkpoint had no token_embedding.weight)"; return FE_ERR_NOT_LOADED; }
+  FE_CHECK(tokens && features && n > 0 && ctx_len == C.clip_text->ctx, "bad arguments (context length must be %d)", C.clip_text->ctx);
+  const int od = C.clip_text->out_dim;
+  std::vector<int> eot(n);
+  for (int b = 0; b < n; ++b) {   // text.argmax(dim=-1): first position of the largest token id (the EOT token)
+    int best = 0;
+    for (int t = 1; t < ctx_len; ++t)
+      if (tokens[(size_t)b * ctx_len + t] > tokens[(size_t)b * ctx_len + best]) best = t;
+    eot[b] = best;
+  }
+  float* d_out = ctx->out_buf((size_t)n * od);
+  const int mb = std::max(1, ctx->microbatch * 4);
+  for (int i0 = 0; i0 < n; i0 += mb) {
+    const int nb = std::min(mb, n - i0);
+    C.arena.reset();
+    int* d_tok = (int*)C.arena.alloc((size_t)nb * ctx_len * sizeof(int));
+    int* d_eot = (int*)C.arena.alloc((size_t)nb * sizeof(int));
+    FE_HIP(hipMemcpyAsync(d_tok, tokens + (size_t)i0 * ctx_len, (size_t)nb * ctx_len * sizeof(int), hipMemcpyHostToDevice, C.stream));
+    FE_HIP(hipMemcpyAsync(d_eot, eot.data() + i0, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, C.stream));
+    clip_text_forward(C, *C.clip_text, d_tok, d_eot, nb, d_out + (size_t)i0 * od);
+    FE_HIP(hipStreamSynchronize(C.stream));
+  }
+  FE_HIP(hipMemcpyAsync(features, d_out, (size_t)n * od * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipStreamSynchronize(C.stream));
   FE_API_END(ctx)
 }

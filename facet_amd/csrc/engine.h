@@ -67,7 +67,7 @@ struct MHAW {
 MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& prefix, int heads);
 // y[B*Lq][d] = res + out_proj(softmax(q k^T / sqrt(hd)) v); q from q_in, k/v from kv_in (rows = tokens).
 void mha_forward(Ctx& c, const MHAW& m, const float* q_in, int ldq, const float* kv_in, int ldkv, int B, int Lq,
-                 int Lk, const float* res, int ldr, float* y, int ldy);
+                 int Lk, const float* res, int ldr, float* y, int ldy, bool causal = false);
 // y[M][N] = act(x[M][K] W^T + b) (+res)
 void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act,
                     const float* res = nullptr, int ldr = 0);
@@ -128,6 +128,7 @@ struct Ctx {
   std::unique_ptr<struct SampModel> samp;
   std::unique_ptr<struct ClipModel> clip;
   std::unique_ptr<struct AestheticModel> aesthetic;
+  std::unique_ptr<struct ClipTextModel> clip_text;
   ~Ctx();
 };
 
@@ -185,6 +186,19 @@ struct ClipModel {
   int width = 0, heads = 0, tokens = 0, patch_size = 0, out_dim = 0;
 };
 struct AestheticModel { DeviceWeights dw; ConvW l0, l2; };
+// CLIP text tower (open_clip TextTransformer: causal, pooled at the EOT token) — SURVEY §8(f)-3
+struct ClipTextModel {
+  DeviceWeights dw;
+  float* tok_emb = nullptr;   // [vocab][width]
+  float* pos = nullptr;       // [ctx][width]
+  std::vector<ClipBlockW> blocks;
+  LayerNormW ln_final;
+  ConvW proj;
+  int vocab = 0, width = 0, ctx = 0, heads = 0, out_dim = 0;
+};
+void build_clip_text(ClipTextModel& m, const WeightStore& ws);
+// tokens: device int32 [B][ctx]; eot: device int32 [B] (argmax position per row); feat: device [B][out_dim]
+void clip_text_forward(Ctx& c, const ClipTextModel& m, const int* tokens, const int* eot, int B, float* feat);
 void build_clip(ClipModel& m, const WeightStore& ws);
 void build_aesthetic(AestheticModel& m, const WeightStore& ws);
 void clip_forward(Ctx& c, const ClipModel& m, const Tensor& x_nhwc4, float* feat);

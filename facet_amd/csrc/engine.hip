@@ -340,7 +340,7 @@ static void raw_gemm(Ctx& c, ConvParams& p, double flops) {
 }
 
 void mha_forward(Ctx& c, const MHAW& m, const float* q_in, int ldq, const float* kv_in, int ldkv, int B, int Lq, int Lk,
-                 const float* res, int ldr, float* y, int ldy) {
+                 const float* res, int ldr, float* y, int ldy, bool causal) {
   const int d = m.d, H = m.heads, hd = d / H;
   const int Lp = (Lk + 31) / 32 * 32;  // padded key count: row stride of the score matrix and of V^T
   const size_t mark = c.arena.mark();
@@ -349,6 +349,7 @@ void mha_forward(Ctx& c, const MHAW& m, const float* q_in, int ldq, const float*
   float* Vt = (float*)c.arena.alloc((size_t)B * d * Lp * sizeof(float));
   static const bool no_flash = getenv("FE_NO_FLASH") != nullptr;
   const bool flash = (hd == 64) && !no_flash;
+  FE_CHECK(flash || !causal, "causal attention needs the fused kernel (head_dim 64)");
   float* S = flash ? nullptr : (float*)c.arena.alloc((size_t)B * H * Lq * Lp * sizeof(float));
   float* O = (float*)c.arena.alloc((size_t)B * Lq * d * sizeof(float));
   linear_forward(c, m.q, q_in, ldq, B * Lq, Q, d, ACT_NONE);
@@ -363,7 +364,7 @@ void mha_forward(Ctx& c, const MHAW& m, const float* q_in, int ldq, const float*
   }
   if (flash) {
     // fused QK^T -> online softmax -> PV (kernels_attn.hip); scores never touch HBM
-    launch_attention(Q, d, K, d, Vt, Lp, m.bv, O, d, B, H, Lq, Lk, d, c.stream);
+    launch_attention(Q, d, K, d, Vt, Lp, m.bv, O, d, B, H, Lq, Lk, d, causal ? 1 : 0, c.stream);
     c.flops_accum += 4.0 * B * H * (double)Lq * Lk * hd;
   } else {
   {  // S[b,h] [Lq][Lk] = Q_bh K_bh^T

@@ -172,7 +172,7 @@ void launch_tap_gather(const float* z, int ldz, int n, int h, int w, int kh, int
                        hipStream_t s);
 // fused attention, head_dim 64 (kernels_attn.hip): o = softmax(q k^T) v + bv per (batch, head)
 void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* vt, int lp, const float* bv, float* o,
-                      int ldo, int B, int H, int Lq, int Lk, int dmodel, hipStream_t s);
+                      int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s);
 // M <= 32 rows: one wave per output column (kernels_misc.hip)
 void launch_gemm_skinny(const float* x, int ldx, const float* w, int ldw, const float* scale, const float* shift, float* y,
                         int ldy, int M, int N, int K, int act, hipStream_t s);

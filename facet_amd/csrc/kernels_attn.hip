@@ -26,6 +26,7 @@ struct AttnParams {
   const float* bv;             // [d_model] V bias, added to the output (softmax rows sum to 1)
   float* o; int ldo;           // [B*Lq][ldo]
   int B, H, Lq, Lk, dmodel;
+  int causal;                  // 1: key j is visible to query i only if j <= i (CLIP text tower)
 };
 
 template <int NW>
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = kbase + (e & 3) + 8 * (e >> 2);
-      if (key >= p.Lk) st[e] = -INFINITY;
+      if (key >= p.Lk || (p.causal && key > q)) st[e] = -INFINITY;
       tmax = fmaxf(tmax, st[e]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
@@ -164,11 +165,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
 }
 
 void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* vt, int lp, const float* bv, float* o,
-                      int ldo, int B, int H, int Lq, int Lk, int dmodel, hipStream_t s) {
+                      int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s) {
   FE_CHECK(dmodel == H * 64, "attention kernel is built for head_dim 64 (d_model %d, %d heads)", dmodel, H);
   FE_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && lp % 4 == 0 && ldo % 4 == 0 && lp >= (Lk + 31) / 32 * 32, "attention: strides");
   FE_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)bv | (uintptr_t)o) & 15) == 0, "attention: alignment");
-  AttnParams p{q, ldq, k, ldk, vt, lp, bv, o, ldo, B, H, Lq, Lk, dmodel};
+  AttnParams p{q, ldq, k, ldk, vt, lp, bv, o, ldo, B, H, Lq, Lk, dmodel, causal};
   // 4 waves (128 queries) per workgroup when that wastes little; 2 waves for short / ragged sequences (CLIP: 257)
   const int w4 = (Lq + 127) / 128 * 128, w2 = (Lq + 63) / 64 * 64;
   if (w4 * 100 <= w2 * 108) {

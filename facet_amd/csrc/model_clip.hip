@@ -48,6 +48,88 @@ void build_clip(ClipModel& m, const WeightStore& ws) {
   m.proj = build_linear_rows(m.dw, prt, nullptr, 0, m.out_dim);
 }
 
+void build_clip_text(ClipTextModel& m, const WeightStore& ws) {
+  const HostTensor& te = ws.get("token_embedding.weight");
+  m.vocab = (int)te.shape[0]; m.width = (int)te.shape[1];
+  m.tok_emb = m.dw.upload(te.data);
+  const HostTensor& pe = ws.get("positional_embedding");
+  m.ctx = (int)pe.shape[0];
+  FE_CHECK((int)pe.shape[1] == m.width && m.width % 64 == 0, "clip text: positional_embedding width mismatch");
+  m.pos = m.dw.upload(pe.data);
+  m.heads = m.width / 64;
+  for (int i = 0;; ++i) {
+    const std::string b = "transformer.resblocks." + std::to_string(i);
+    if (!ws.has(b + ".ln_1.weight")) break;
+    ClipBlockW w;
+    w.ln1 = build_ln(m.dw, ws, b + ".ln_1");
+    w.ln2 = build_ln(m.dw, ws, b + ".ln_2");
+    w.attn = build_mha(m.dw, ws, b + ".attn", m.heads);
+    w.fc = build_linear(m.dw, ws, b + ".mlp.c_fc", true);
+    w.proj = build_linear(m.dw, ws, b + ".mlp.c_proj", true);
+    m.blocks.push_back(w);
+  }
+  FE_CHECK(!m.blocks.empty(), "clip text: no transformer blocks found");
+  m.ln_final = build_ln(m.dw, ws, "ln_final");
+  const HostTensor& pr = ws.get("text_projection");   // [width][out]: features = pooled @ text_projection
+  HostTensor prt;
+  prt.shape = {pr.shape[1], pr.shape[0]};
+  prt.data.resize(pr.data.size());
+  for (int i = 0; i < pr.shape[0]; ++i)
+    for (int j = 0; j < pr.shape[1]; ++j) prt.data[(size_t)j * pr.shape[0] + i] = pr.data[(size_t)i * pr.shape[1] + j];
+  m.out_dim = (int)pr.shape[1];
+  m.proj = build_linear_rows(m.dw, prt, nullptr, 0, m.out_dim);
+}
+
+// x[b][t][:] = tok_emb[tokens[b][t]][:] + pos[t][:]
+__global__ void text_embed_kernel(const int* __restrict__ tokens, const float* __restrict__ emb, const float* __restrict__ pos,
+                                  float* __restrict__ x, int rows, int ctx, int d, int vocab) {
+  const size_t total = (size_t)rows * d;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % d;
+    const int row = i / d;
+    int tk = tokens[row];
+    tk = tk < 0 ? 0 : (tk >= vocab ? vocab - 1 : tk);
+    x[i] = emb[(size_t)tk * d + c] + pos[(size_t)(row % ctx) * d + c];
+  }
+}
+// pooled[b][:] = x[b][eot[b]][:]
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ eot, float* __restrict__ y, int B,
+                                   int ctx, int d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * d) return;
+  const int b = i / d, c = i % d;
+  int e = eot[b];
+  e = e < 0 ? 0 : (e >= ctx ? ctx - 1 : e);
+  y[i] = x[((size_t)b * ctx + e) * d + c];
+}
+
+void clip_text_forward(Ctx& c, const ClipTextModel& m, const int* tokens, const int* eot, int B, float* feat) {
+  const size_t mark = c.arena.mark();
+  const int d = m.width, T = m.ctx, rows = B * T;
+  float* xa = (float*)c.arena.alloc((size_t)rows * d * sizeof(float));
+  float* xb = (float*)c.arena.alloc((size_t)rows * d * sizeof(float));
+  float* nb = (float*)c.arena.alloc((size_t)rows * d * sizeof(float));
+  float* hb = (float*)c.arena.alloc((size_t)rows * 4 * d * sizeof(float));
+  hipLaunchKernelGGL(text_embed_kernel, dim3(1024), dim3(256), 0, c.stream, tokens, m.tok_emb, m.pos, xa, rows, T, d, m.vocab);
+  FE_HIP(hipGetLastError());
+  float* cur = xa;
+  float* other = xb;
+  for (const ClipBlockW& w : m.blocks) {
+    launch_layernorm(cur, d, nb, d, w.ln1.g, w.ln1.b, rows, d, w.ln1.eps, c.stream);
+    mha_forward(c, w.attn, nb, d, nb, d, B, T, T, cur, d, other, d, /*causal=*/true);
+    launch_layernorm(other, d, nb, d, w.ln2.g, w.ln2.b, rows, d, w.ln2.eps, c.stream);
+    linear_forward(c, w.fc, nb, d, rows, hb, w.fc.Cout, ACT_GELU);
+    linear_forward(c, w.proj, hb, w.fc.Cout, rows, cur, d, ACT_NONE, other, d);
+  }
+  float* pooled = (float*)c.arena.alloc((size_t)B * d * sizeof(float));
+  float* pn = (float*)c.arena.alloc((size_t)B * d * sizeof(float));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((B * d + 255) / 256), dim3(256), 0, c.stream, cur, eot, pooled, B, T, d);
+  FE_HIP(hipGetLastError());
+  launch_layernorm(pooled, d, pn, d, m.ln_final.g, m.ln_final.b, B, d, m.ln_final.eps, c.stream);   // LN is per row: gather first
+  linear_forward(c, m.proj, pn, d, B, feat, m.out_dim, ACT_NONE);
+  c.arena.rewind(mark);
+}
+
 void build_aesthetic(AestheticModel& m, const WeightStore& ws) {
   m.l0 = build_linear(m.dw, ws, "0", true);
   m.l2 = build_linear(m.dw, ws, "2", true);

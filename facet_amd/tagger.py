@@ -33,6 +33,16 @@ class CLIPTagger:
                 texts.append(f"a photo of {d}")
         return names, texts
 
+    def precompute_text_embeddings(self, tokenizer):
+        """Reference _precompute_text_embeddings (:51-75) with an injected tokenizer (open_clip.get_tokenizer('ViT-L-14')
+        where available): prompts -> tokens -> clip_model.encode_text on the engine -> L2-normalised rows."""
+        if self.model is None:
+            return
+        names, texts = self.prompts()
+        feats = self.model.encode_text(tokenizer(texts))
+        feats = feats.detach().cpu().numpy() if hasattr(feats, "detach") else np.asarray(feats)
+        self.set_text_embeddings(names, feats)
+
     def set_text_embeddings(self, tag_names, embeddings):
         e = np.asarray(embeddings, np.float32)
         self.text_embeddings = e / np.linalg.norm(e, axis=-1, keepdims=True)

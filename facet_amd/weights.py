@@ -143,6 +143,23 @@ def clip_vit_spec(width=1024, layers=24, patch=14, grid=16, out_dim=768):
     return spec
 
 
+def clip_text_spec(width=768, layers=12, ctx=77, vocab=49408, out_dim=768):
+    """open_clip CLIP text tower keys (top level of the CLIP checkpoint, next to `visual.*`) [DEP-KNOWLEDGE]."""
+    spec = [("token_embedding.weight", (vocab, width), "emb"), ("positional_embedding", (ctx, width), "emb")]
+    for i in range(layers):
+        b = f"transformer.resblocks.{i}"
+        _ln(spec, b + ".ln_1", width)
+        spec.append((b + ".attn.in_proj_weight", (3 * width, width), "linear"))
+        spec.append((b + ".attn.in_proj_bias", (3 * width,), "bias"))
+        _linear(spec, b + ".attn.out_proj", width, width)
+        _ln(spec, b + ".ln_2", width)
+        _linear(spec, b + ".mlp.c_fc", width * 4, width)
+        _linear(spec, b + ".mlp.c_proj", width, width * 4)
+    _ln(spec, "ln_final", width)
+    spec.append(("text_projection", (width, out_dim), "proj"))
+    return spec
+
+
 def aesthetic_spec():
     """Linear(768,256)-ReLU-Linear(256,1), reference processing/scorer.py:579-583."""
     spec = []
@@ -208,6 +225,8 @@ SPECS = {
     "topiq": topiq_spec,
     "resnet50": lambda: resnet_spec("semantic_model.", True, [3, 4, 6, 3]),
     "clip": clip_vit_spec,
+    "clip_text": clip_text_spec,
+    "clip_full": lambda: clip_vit_spec() + clip_text_spec(),
     "aesthetic": aesthetic_spec,
     "u2netp": u2netp_spec,
     "samp_net": sampnet_spec,

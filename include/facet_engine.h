@@ -145,6 +145,11 @@ int fe_clip_encode_images(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, 
  * Resize((224,224)), ToTensor, ImageNet Normalize, U2NETP saliency, SAMPNet. Outputs as fe_samp_forward. */
 int fe_samp_score_images(fe_ctx* ctx, const uint8_t* img, int n, int h, int w, int bgr, int on_device,
                          float* pattern_weights, float* attributes, float* score_dist);
+/* CLIP text tower (built when the FE_MODEL_CLIP checkpoint carries token_embedding.weight): tokens int32 [n][77] ->
+ * un-normalised text features [n][768]. Replaces `clip_model.encode_text(tokens)` (models/tagger.py:69-75); pooling is
+ * at argmax(token id) = the EOT token, as open_clip does. */
+int fe_clip_encode_text(fe_ctx* ctx, const int32_t* tokens, int n, int ctx_len, float* features);
+
 /* Batched tag scoring: sims[n][T] = emb[n][d] . text[T][d]^T. Replaces the per-image matmul + loop of
  * CLIPTagger.get_tags_from_embedding (models/tagger.py:100-106); selection (max over synonyms, threshold, top-k) stays on host. */
 int fe_tag_similarities(fe_ctx* ctx, const float* emb, int n, const float* text, int T, int d, float* sims);

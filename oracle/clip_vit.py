@@ -68,6 +68,30 @@ class VisionTransformer(nn.Module):
         return self.ln_post(x[:, 0]) @ self.proj
 
 
+class TextTransformer(nn.Module):
+    """open_clip text tower for ViT-L-14: width 768, 12 layers, 12 heads, context 77, causal mask, features taken at the
+    EOT token (argmax of the token ids), `@ text_projection`. Reference call: `encode_text` (models/tagger.py:73)."""
+
+    def __init__(self, width=768, layers=12, heads=12, ctx=77, vocab=49408, out_dim=768):
+        super().__init__()
+        self.token_embedding = nn.Embedding(vocab, width)
+        self.positional_embedding = nn.Parameter(torch.zeros(ctx, width))
+        self.transformer = _Transformer(width, layers, heads)
+        self.ln_final = nn.LayerNorm(width)
+        self.text_projection = nn.Parameter(torch.zeros(width, out_dim))
+        self.register_buffer("attn_mask", torch.full((ctx, ctx), float("-inf")).triu_(1), persistent=False)
+
+    def forward(self, text):
+        x = self.token_embedding(text) + self.positional_embedding
+        x = x.permute(1, 0, 2)
+        for blk in self.transformer.resblocks:
+            y = blk.ln_1(x)
+            x = x + blk.attn(y, y, y, need_weights=False, attn_mask=self.attn_mask)[0]
+            x = x + blk.mlp(blk.ln_2(x))
+        x = self.ln_final(x.permute(1, 0, 2))
+        return x[torch.arange(x.shape[0]), text.argmax(dim=-1)] @ self.text_projection
+
+
 class CLIPImage(nn.Module):
     """Holds the tower under `visual.` like open_clip's CLIP so checkpoint keys match."""
 
