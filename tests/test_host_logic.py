@@ -105,3 +105,26 @@ def test_model_manager_pass_packing_and_profiles():
     assert [mm.get_recommended_profile(v) for v in (288, 16, 8, 2)] == ["24gb", "16gb", "8gb", "legacy"]
     assert mm.select_quality_model(24) == "topiq" and mm._cache_hits == 0 and mm._cache_misses == 0
     assert mm.load_model_only("nope") is None and mm._cache_misses == 1   # failure -> None, caller raises (multi_pass.py:344-348)
+
+
+def test_face_analyzer_mirror_unavailable_contract_and_ear():
+    """No detector in the engine yet: the mirror behaves like the reference when InsightFace is missing (face.py:90-97),
+    and the EAR arithmetic (face.py:241-256) is exact on hand-made landmarks."""
+    from facet_amd.face import FaceAnalyzer
+    fa = FaceAnalyzer(min_confidence=0.65, blink_ear_threshold=0.28)
+    assert fa.available is False
+    r = fa.analyze_faces(np.zeros((64, 64, 3), np.uint8))
+    assert r["face_count"] == 0 and r["bbox"] is None and r["face_details"] == [] and len(r) == 11
+    lm = np.zeros((106, 2), np.float32)
+    for idx in (FaceAnalyzer.LEFT_EYE_INDICES, FaceAnalyzer.RIGHT_EYE_INDICES):
+        outer, inner, u1, u2, l1, l2 = idx
+        lm[outer] = (0, 0); lm[inner] = (10, 0)          # eye width 10
+        lm[u1] = (3, 2); lm[l1] = (3, -1)                # vertical 3
+        lm[u2] = (7, 1.5); lm[l2] = (7, -1.5)            # vertical 3
+    assert FaceAnalyzer.compute_avg_ear(lm) == pytest.approx(0.3)
+    assert FaceAnalyzer.calculate_ear(np.zeros((106, 2)), FaceAnalyzer.LEFT_EYE_INDICES) == 0.3   # degenerate width
+    face = type("F", (), {"landmark_2d_106": lm})()
+    assert not fa.is_blinking(face)
+    lm2 = lm.copy(); lm2[:, 1] *= 0.5
+    assert fa.is_blinking(type("F", (), {"landmark_2d_106": lm2})())
+    assert not fa.is_blinking(object())
