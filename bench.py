@@ -28,16 +28,37 @@ METRIC = "images/sec whole-node (TOPIQ+SAMP+CLIP+InsightFace ensemble), 1024² b
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-def cpu_baseline(sample, hw, seed_w):
-    """Oracle (torch-CPU fp32 port of TOPIQ) on a bounded sample, one image per forward like the reference's
-    PyIQAScorer.score_batch loop (models/pyiqa_scorer.py:245-253)."""
+def cpu_baseline(sample, hw, seed_w, workload="topiq"):
+    """Oracle (torch-CPU fp32 port) on a bounded sample with the reference's calling pattern: TOPIQ and SAMP-Net one
+    image per forward (models/pyiqa_scorer.py:245-253, processing/multi_pass.py:540-547), CLIP batched per chunk
+    (multi_pass.py:518-525); preprocessing with PIL like the reference."""
     import torch
     from facet_amd.weights import synthetic_state_dict, synthetic_images
     from oracle.topiq import CFANet
-    net = CFANet().eval()
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict("topiq", seed_w).items()})
+    ld = lambda net, name: (net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(name, seed_w).items()}),
+                            net.eval())[1]
+    net = ld(CFANet(), "topiq")
     imgs = synthetic_images(2, sample, hw, hw)
     cores = torch.get_num_threads()
+    extra = None
+    if workload == "ensemble":
+        from PIL import Image
+        from oracle.clip_vit import CLIPImage, aesthetic_head, CLIP_MEAN, CLIP_STD
+        from oracle.sampnet import U2NETP, SAMPNet
+        clip, head, u2, sn = ld(CLIPImage(), "clip"), ld(aesthetic_head(), "aesthetic"), ld(U2NETP(), "u2netp"), ld(SAMPNet(), "samp_net")
+        im_m, im_s = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+        cl_m, cl_s = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+
+        def extra(batch):
+            pils = [Image.fromarray(a) for a in batch]
+            c_in = torch.stack([torch.from_numpy(np.asarray(p.resize((224, 224), Image.BICUBIC), np.float32) / 255).permute(2, 0, 1)
+                                for p in pils])
+            f = clip.encode_image((c_in - cl_m) / cl_s)
+            head(f)
+            for p in pils:
+                x = torch.from_numpy(np.asarray(p.resize((224, 224), Image.BILINEAR), np.float32) / 255).permute(2, 0, 1)[None]
+                x = (x - im_m) / im_s
+                sn(x, u2(x))
     with torch.no_grad():
         x = torch.from_numpy(imgs[:1].astype(np.float32) / 255.0).permute(0, 3, 1, 2)
         net(x)  # warm
@@ -45,10 +66,13 @@ def cpu_baseline(sample, hw, seed_w):
         for i in range(sample):
             x = torch.from_numpy(imgs[i:i + 1].astype(np.float32) / 255.0).permute(0, 3, 1, 2)
             net(x)
+        if extra is not None:
+            extra(imgs)
         dt = time.perf_counter() - t0
+    what = "oracle/topiq.py CFANet" if workload == "topiq" else "oracle TOPIQ + CLIP ViT-L/14 + aesthetic MLP + U2NETP + SAMPNet"
     return {"value": round(sample / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{sample} x {hw}x{hw} synthetic RGB through oracle/topiq.py CFANet (torch {torch.__version__} CPU "
-                      f"fp32, {cores} threads, one image per forward)"}
+            "sample": f"{sample} x {hw}x{hw} synthetic RGB through {what} (torch {torch.__version__} CPU fp32, {cores} "
+                      "threads; TOPIQ/SAMP one image per forward, CLIP one batch)"}
 
 
 def main():
@@ -174,8 +198,8 @@ def main():
                          "flops_per_image": round(flops / (B * args.steps), 1),
                          "event_ms": round(ev_ms, 3)},
         }
-        if args.cpu_sample > 0 and args.workload == "topiq":
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, HW, 3)
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, HW, 3, args.workload)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
