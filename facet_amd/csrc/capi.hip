@@ -9,6 +9,12 @@ struct fe_ctx {
   Ctx c;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   int microbatch = 8;
+  // double-buffered H2D staging of uint8 micro-batches on a copy stream (host-buffer entry points): the copy of
+  // micro-batch k+1 is issued right after the kernels of micro-batch k were queued, so PCIe overlaps compute
+  hipStream_t copy_stream = nullptr;
+  uint8_t* stage_buf[2] = {nullptr, nullptr};
+  size_t stage_cap[2] = {0, 0};
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
   float* d_out = nullptr;   // persistent device staging for per-image results
   size_t d_out_cap = 0;
   float* out_buf(size_t floats) {
@@ -23,6 +29,58 @@ struct fe_ctx {
 };
 
 static std::string g_create_err;
+
+// Walks a uint8 image batch micro-batch by micro-batch. Device-resident input: pointer arithmetic. Host input: ping-pong
+// device buffers filled on the copy stream; get(k) makes the compute stream wait for chunk k, done(k) marks its last
+// consumer and starts the copy of chunk k+1 (which then runs under the kernels just queued for chunk k).
+class ImageStager {
+ public:
+  ImageStager(fe_ctx* ctx, const uint8_t* imgs, int n, size_t per_image, int mb, int on_device)
+      : x_(ctx), imgs_(imgs), n_(n), per_(per_image), mb_(mb), dev_(on_device) {
+    if (!dev_) {
+      if (!x_->copy_stream) {
+        FE_HIP(hipStreamCreateWithFlags(&x_->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+          FE_HIP(hipEventCreateWithFlags(&x_->ev_copied[i], hipEventDisableTiming));
+          FE_HIP(hipEventCreateWithFlags(&x_->ev_consumed[i], hipEventDisableTiming));
+        }
+      }
+      const size_t need = (size_t)std::min(mb_, n_) * per_;
+      for (int i = 0; i < 2; ++i)
+        if (x_->stage_cap[i] < need) {
+          FE_HIP(hipStreamSynchronize(x_->c.stream));
+          if (x_->stage_buf[i]) FE_HIP(hipFree(x_->stage_buf[i]));
+          x_->stage_buf[i] = nullptr; x_->stage_cap[i] = 0;
+          FE_HIP(hipMalloc((void**)&x_->stage_buf[i], need));
+          x_->stage_cap[i] = need;
+        }
+      issue(0);
+    }
+  }
+  int chunks() const { return (n_ + mb_ - 1) / mb_; }
+  int count(int k) const { return std::min(mb_, n_ - k * mb_); }
+  const uint8_t* get(int k) {
+    if (dev_) return imgs_ + (size_t)k * mb_ * per_;
+    FE_HIP(hipStreamWaitEvent(x_->c.stream, x_->ev_copied[k & 1], 0));
+    return x_->stage_buf[k & 1];
+  }
+  void done(int k) {
+    if (dev_) return;
+    FE_HIP(hipEventRecord(x_->ev_consumed[k & 1], x_->c.stream));
+    consumed_[k & 1] = true;
+    if (k + 1 < chunks()) issue(k + 1);
+  }
+ private:
+  void issue(int k) {
+    const int b = k & 1;
+    if (consumed_[b]) FE_HIP(hipStreamWaitEvent(x_->copy_stream, x_->ev_consumed[b], 0));
+    FE_HIP(hipMemcpyAsync(x_->stage_buf[b], imgs_ + (size_t)k * mb_ * per_, (size_t)count(k) * per_, hipMemcpyHostToDevice,
+                          x_->copy_stream));
+    FE_HIP(hipEventRecord(x_->ev_copied[b], x_->copy_stream));
+  }
+  fe_ctx* x_; const uint8_t* imgs_; int n_; size_t per_; int mb_, dev_;
+  bool consumed_[2] = {false, false};
+};
 
 // every entry point re-selects the context's device: the calling thread may share the process with torch / RCCL
 #define FE_API_BEGIN(ctx)                         \
@@ -75,6 +133,12 @@ void fe_destroy(fe_ctx* ctx) {
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->stage_buf[i]) (void)hipFree(ctx->stage_buf[i]);
+    if (ctx->ev_copied[i]) (void)hipEventDestroy(ctx->ev_copied[i]);
+    if (ctx->ev_consumed[i]) (void)hipEventDestroy(ctx->ev_consumed[i]);
+  }
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   delete ctx;
 }
 
@@ -442,20 +506,15 @@ int fe_topiq_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_
   // scores of all micro-batches accumulate in a small device buffer outside the arena; one D2H at the end
   float* d_scores = ctx->out_buf((size_t)n);
   {
-    for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
-      const int nb = std::min(ctx->microbatch, n - i0);
+    ImageStager st(ctx, rgb, n, img_bytes, ctx->microbatch, on_device);
+    for (int k = 0; k < st.chunks(); ++k) {
+      const int i0 = k * ctx->microbatch, nb = st.count(k);
       C.arena.reset();
-      const uint8_t* d_in;
-      if (on_device) {
-        d_in = rgb + (size_t)i0 * img_bytes;
-      } else {
-        uint8_t* d = (uint8_t*)C.arena.alloc(nb * img_bytes);
-        FE_HIP(hipMemcpyAsync(d, rgb + (size_t)i0 * img_bytes, nb * img_bytes, hipMemcpyHostToDevice, C.stream));
-        d_in = d;
-      }
+      const uint8_t* d_in = st.get(k);
       std::vector<Tensor> feats;
       topiq_backbone_chunk(ctx, d_in, nb, h, w, feats);
       topiq_head_forward(C, *C.topiq, feats, d_scores + i0);
+      st.done(k);
     }
     FE_HIP(hipMemcpyAsync(scores, d_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, C.stream));
     FE_HIP(hipStreamSynchronize(C.stream));
@@ -599,13 +658,6 @@ static Tensor preprocess_square224(Ctx& C, const uint8_t* d_rgb, int nb, int h, 
   return x;
 }
 
-static const uint8_t* stage_images(Ctx& C, const uint8_t* imgs, size_t bytes, int on_device) {
-  if (on_device) return imgs;
-  uint8_t* d = (uint8_t*)C.arena.alloc(bytes);
-  FE_HIP(hipMemcpyAsync(d, imgs, bytes, hipMemcpyHostToDevice, C.stream));
-  return d;
-}
-
 // CLIP from raw images: open_clip eval transform (bicubic shorter-side 224, center crop, CLIP mean/std) + tower.
 int fe_clip_encode_images(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* features,
                           float* emb_norm, float* aesthetic_raw) {
@@ -618,11 +670,13 @@ int fe_clip_encode_images(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, 
   const size_t per = (size_t)h * w * 3;
   float* d_out = ctx->out_buf((size_t)n * (2 * od + 1));
   float* d_feat = d_out; float* d_norm = d_out + (size_t)n * od; float* d_aes = d_out + (size_t)n * 2 * od;
-  for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
-    const int nb = std::min(ctx->microbatch, n - i0);
+  ImageStager st(ctx, rgb, n, per, ctx->microbatch, on_device);
+  for (int k = 0; k < st.chunks(); ++k) {
+    const int i0 = k * ctx->microbatch, nb = st.count(k);
     C.arena.reset();
-    const uint8_t* d_in = stage_images(C, rgb + (size_t)i0 * per, nb * per, on_device);
+    const uint8_t* d_in = st.get(k);
     Tensor xt = preprocess_square224(C, d_in, nb, h, w, FE_FILTER_BICUBIC, true, kClipMean, kClipStd, 0);
+    st.done(k);   // the raw images are consumed by the resize kernels queued above
     clip_forward(C, *C.clip, xt, d_feat + (size_t)i0 * od);
     if (emb_norm) l2_normalize(C, d_feat + (size_t)i0 * od, d_norm + (size_t)i0 * od, nb, od);
     if (aesthetic_raw) aesthetic_forward(C, *C.aesthetic, d_feat + (size_t)i0 * od, nb, d_aes + i0);
@@ -644,11 +698,13 @@ int fe_samp_score_images(fe_ctx* ctx, const uint8_t* img, int n, int h, int w, i
   FE_CHECK(img && n > 0 && pattern_weights && attributes && score_dist, "bad arguments");
   const size_t per = (size_t)h * w * 3;
   float* d_out = ctx->out_buf((size_t)n * 19);
-  for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
-    const int nb = std::min(ctx->microbatch, n - i0);
+  ImageStager st(ctx, img, n, per, ctx->microbatch, on_device);
+  for (int k = 0; k < st.chunks(); ++k) {
+    const int i0 = k * ctx->microbatch, nb = st.count(k);
     C.arena.reset();
-    const uint8_t* d_in = stage_images(C, img + (size_t)i0 * per, nb * per, on_device);
+    const uint8_t* d_in = st.get(k);
     Tensor xt = preprocess_square224(C, d_in, nb, h, w, FE_FILTER_BILINEAR, false, kImagenetMean, kImagenetStd, bgr);
+    st.done(k);
     Tensor sal = C.arena.tensor(nb, 224, 224, 1);
     u2netp_forward(C, *C.u2netp, xt, sal);
     sampnet_forward(C, *C.samp, xt, sal, d_out + (size_t)i0 * 8, d_out + (size_t)n * 8 + (size_t)i0 * 6,
@@ -730,10 +786,11 @@ int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
   const bool do_topiq = C.topiq && C.topiq->has_head, do_clip = (bool)C.clip, do_samp = C.samp && C.u2netp;
   float* p_topiq = d_rec;  float* p_aes = d_rec + o_aes;  float* p_pw = d_rec + o_pw;  float* p_at = d_rec + o_at;
   float* p_sd = d_rec + o_sd;  float* p_emb = d_rec + o_emb;  float* d_feat = d_rec + o_feat;
-  for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
-    const int nb = std::min(ctx->microbatch, n - i0);
+  ImageStager st(ctx, rgb, n, per, ctx->microbatch, on_device);
+  for (int k = 0; k < st.chunks(); ++k) {
+    const int i0 = k * ctx->microbatch, nb = st.count(k);
     C.arena.reset();
-    const uint8_t* d_in = stage_images(C, rgb + (size_t)i0 * per, nb * per, on_device);
+    const uint8_t* d_in = st.get(k);
     if (do_topiq) {
       const size_t mark = C.arena.mark();
       std::vector<Tensor> feats;
@@ -757,6 +814,7 @@ int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
       sampnet_forward(C, *C.samp, xt, sal, p_pw + (size_t)i0 * 8, p_at + (size_t)i0 * 6, p_sd + (size_t)i0 * 5);
       C.arena.rewind(mark);
     }
+    st.done(k);
   }
   std::vector<float> host(o_feat);
   FE_HIP(hipMemcpyAsync(host.data(), d_rec, host.size() * sizeof(float), hipMemcpyDeviceToHost, C.stream));
