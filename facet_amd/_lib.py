@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libfacet_engine.so")
 FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_SAMP, FE_MODEL_U2NETP, FE_MODEL_AESTHETIC = range(5)
 FE_MODEL_SCRFD, FE_MODEL_ARCFACE = 5, 6
 FE_RECORD_FLOATS = 789
+FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC = 0, 1, 2
 FILTERS = {"lanczos": 1, "bilinear": 2, "bicubic": 3}
 ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3}
 
@@ -81,6 +82,20 @@ SIGNATURES = {
                                     C.POINTER(C.c_int)]),
     "fe_u2netp_saliency": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_samp_forward": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p]),
+    "fe_onnx_probe": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _i64p,
+                                C.c_char_p, C.c_int]),
+    "fe_graph_load": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "fe_graph_unload": (C.c_int, [C.c_void_p, C.c_int]),
+    "fe_graph_loaded": (C.c_int, [C.c_void_p, C.c_int]),
+    "fe_graph_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _i64p, C.POINTER(C.c_int)]),
+    "fe_graph_run": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fe_graph_output_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, _i64p, C.POINTER(C.c_int)]),
+    "fe_graph_output_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _f32p, C.c_size_t]),
+    "fe_face_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                 _f32p, C.POINTER(C.c_int), _f32p]),
+    "fe_face_crops_run": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                    C.POINTER(C.c_double), C.c_int, C.c_float, C.c_float, C.c_int, _f32p, C.c_int, C.c_void_p]),
+    "fe_cv_resize_linear_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 
@@ -112,6 +127,18 @@ def load_library():
 def _f32(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a, a.ctypes.data_as(_f32p)
+
+
+def onnx_probe(onnx_bytes):
+    """Host-only parse of an .onnx buffer -> dict(nodes, initializers, outputs, input_dims). Raises EngineError on a bad file."""
+    lib = load_library()
+    buf = C.create_string_buffer(bytes(onnx_bytes), len(onnx_bytes))
+    nn, ni, no = C.c_int(), C.c_int(), C.c_int()
+    dims = (C.c_int64 * 4)()
+    err = C.create_string_buffer(512)
+    if lib.fe_onnx_probe(buf, len(onnx_bytes), C.byref(nn), C.byref(ni), C.byref(no), dims, err, 512) != 0:
+        raise EngineError(err.value.decode())
+    return {"nodes": nn.value, "initializers": ni.value, "outputs": no.value, "input_dims": list(dims)}
 
 
 class Engine:
@@ -390,6 +417,74 @@ class Engine:
         mask = C.c_int(0)
         self._ck(self.lib.fe_ensemble_score(self.h, p, n, h, w, dev, rec.ctypes.data_as(_f32p), C.byref(mask)))
         return rec, mask.value
+
+    # -- ONNX graphs (InsightFace sessions) -------------------------------------------------------------
+    def graph_load(self, slot, onnx_bytes):
+        buf = C.create_string_buffer(bytes(onnx_bytes), len(onnx_bytes))
+        self._ck(self.lib.fe_graph_load(self.h, int(slot), buf, len(onnx_bytes)))
+
+    def graph_unload(self, slot):
+        self._ck(self.lib.fe_graph_unload(self.h, int(slot)))
+
+    def graph_loaded(self, slot):
+        return bool(self.lib.fe_graph_loaded(self.h, int(slot)))
+
+    def graph_info(self, slot):
+        nn, no, fl = C.c_int(), C.c_int(), C.c_int()
+        dims = (C.c_int64 * 4)()
+        self._ck(self.lib.fe_graph_info(self.h, int(slot), C.byref(nn), C.byref(no), dims, C.byref(fl)))
+        return {"nodes": nn.value, "outputs": no.value, "input_dims": list(dims), "has_sub": bool(fl.value & 1),
+                "has_mul": bool(fl.value & 2)}
+
+    def graph_run(self, slot, x):
+        """x: float32 [n,c,h,w] -> list of numpy outputs in the model's declared order (ONNX layouts)."""
+        x, xp = _f32(x)
+        n, c, h, w = x.shape
+        self._ck(self.lib.fe_graph_run(self.h, int(slot), xp, n, c, h, w, 0))
+        outs = []
+        for i in range(self.graph_info(slot)["outputs"]):
+            dims = (C.c_int64 * 6)()
+            rank = C.c_int()
+            name = C.create_string_buffer(256)
+            self._ck(self.lib.fe_graph_output_info(self.h, int(slot), i, name, 256, dims, C.byref(rank)))
+            shape = tuple(dims[k] for k in range(rank.value))
+            y = np.empty(shape, np.float32)
+            self._ck(self.lib.fe_graph_output_copy(self.h, int(slot), i, y.ctypes.data_as(_f32p), y.size))
+            outs.append(y)
+        return outs
+
+    # -- face path ------------------------------------------------------------------------------------------
+    def face_detect(self, images, det_size=(640, 640), thresh=0.5, max_cand=512):
+        """images: BGR uint8 [n,h,w,3] or (device_ptr,n,h,w). -> (cand [n,max_cand,16], counts [n], det_scale)."""
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        cand = np.zeros((n, max_cand, 16), np.float32)
+        counts = np.zeros((n,), np.int32)
+        ds = C.c_float()
+        self._ck(self.lib.fe_face_detect(self.h, p, n, h, w, dev, int(det_size[0]), int(det_size[1]), float(thresh), int(max_cand),
+                                         cand.ctypes.data_as(_f32p), counts.ctypes.data_as(C.POINTER(C.c_int)), C.byref(ds)))
+        return cand, counts, ds.value
+
+    def face_crops_run(self, slot, images, img_index, M, size, mean, scale, swap_rb=True, out_dim=0, want_crops=False):
+        """M: float64 [m,2,3] forward affine matrices. -> (out [m,out_dim] or None, crops uint8 [m,size,size,3] or None)."""
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        idx = np.ascontiguousarray(img_index, dtype=np.int32)
+        Mm = np.ascontiguousarray(M, dtype=np.float64).reshape(-1, 6)
+        m = idx.shape[0]
+        assert Mm.shape[0] == m
+        out = np.empty((m, out_dim), np.float32) if out_dim else None
+        crops = np.empty((m, size, size, 3), np.uint8) if want_crops else None
+        self._ck(self.lib.fe_face_crops_run(self.h, int(slot), p, n, h, w, dev, m, idx.ctypes.data_as(C.POINTER(C.c_int)),
+                                            Mm.ctypes.data_as(C.POINTER(C.c_double)), int(size), float(mean), float(scale), int(swap_rb),
+                                            out.ctypes.data_as(_f32p) if out_dim else None, int(out_dim),
+                                            crops.ctypes.data_as(C.c_void_p) if want_crops else None))
+        return out, crops
+
+    def cv_resize_linear(self, imgs, oh, ow):
+        a = np.ascontiguousarray(imgs, dtype=np.uint8)
+        n, h, w, _ = a.shape
+        out = np.empty((n, oh, ow, 3), np.uint8)
+        self._ck(self.lib.fe_cv_resize_linear_u8(self.h, a.ctypes.data_as(C.c_void_p), n, h, w, oh, ow, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def tag_similarities(self, emb, text):
         """emb [n,d], text [T,d] (L2-normalised rows) -> cosine similarities [n,T] computed on the GPU."""

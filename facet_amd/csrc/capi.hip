@@ -1,7 +1,9 @@
 // C ABI of libfacet_engine.so (declared in include/facet_engine.h).
 #include "../../include/facet_engine.h"
 #include "engine.h"
+#include "onnx_graph.h"
 #include <cmath>
+#include <tuple>
 
 using namespace fe;
 
@@ -15,6 +17,11 @@ struct fe_ctx {
   uint8_t* stage_buf[2] = {nullptr, nullptr};
   size_t stage_cap[2] = {0, 0};
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+  // face path: device copies of OpenCV's interpolation tables (built once / per size)
+  short* warp_wtab = nullptr;
+  struct CvResizeTab { int* ofs; short* coef; };
+  std::map<std::tuple<int, int, int>, CvResizeTab> cvresize;   // (src, dst, clamp) -> tables
+  std::vector<void*> misc_allocs;
   float* d_out = nullptr;   // persistent device staging for per-image results
   size_t d_out_cap = 0;
   float* out_buf(size_t floats) {
@@ -139,6 +146,7 @@ void fe_destroy(fe_ctx* ctx) {
     if (ctx->ev_consumed[i]) (void)hipEventDestroy(ctx->ev_consumed[i]);
   }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  for (void* q : ctx->misc_allocs) (void)hipFree(q);
   delete ctx;
 }
 
@@ -302,6 +310,108 @@ int fe_model_loaded(fe_ctx* ctx, int model) {
   if (model == FE_MODEL_CLIP) return ctx->c.clip != nullptr;
   if (model == FE_MODEL_AESTHETIC) return ctx->c.aesthetic != nullptr;
   return 0;
+}
+
+// ---- ONNX graphs -------------------------------------------------------------------------------------
+static GraphSlot& graph_slot(fe_ctx* ctx, int slot) {
+  FE_CHECK(slot >= 0 && slot < FE_GRAPH_SLOTS, "graph slot %d out of range", slot);
+  FE_CHECK(ctx->c.graphs[slot], "no graph loaded in slot %d", slot);
+  return *ctx->c.graphs[slot];
+}
+int fe_onnx_probe(const void* onnx_bytes, size_t len, int* n_nodes, int* n_initializers, int* n_outputs, int64_t in_dims[4],
+                  char* err, int err_cap) {
+  try {
+    onnx::Model m;
+    onnx::parse_model((const uint8_t*)onnx_bytes, len, m);
+    if (n_nodes) *n_nodes = (int)m.nodes.size();
+    if (n_initializers) *n_initializers = (int)m.init.size();
+    if (n_outputs) *n_outputs = (int)m.outputs.size();
+    if (in_dims)
+      for (int k = 0; k < 4; ++k) in_dims[k] = k < (int)m.inputs[0].dims.size() ? m.inputs[0].dims[k] : -1;
+  } catch (const std::exception& e) {
+    if (err && err_cap > 0) snprintf(err, err_cap, "%s", e.what());
+    return FE_ERR_RUNTIME;
+  }
+  return FE_OK;
+}
+int fe_graph_load(fe_ctx* ctx, int slot, const void* onnx_bytes, size_t len) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(slot >= 0 && slot < FE_GRAPH_SLOTS && onnx_bytes && len > 0, "bad arguments");
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  FE_HIP(hipStreamSynchronize(ctx->c.stream));
+  auto gs = std::make_unique<GraphSlot>();
+  gs->g.load((const uint8_t*)onnx_bytes, len);
+  ctx->c.graphs[slot] = std::move(gs);
+  FE_API_END(ctx)
+}
+int fe_graph_unload(fe_ctx* ctx, int slot) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(slot >= 0 && slot < FE_GRAPH_SLOTS, "bad arguments");
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  FE_HIP(hipStreamSynchronize(ctx->c.stream));
+  ctx->c.graphs[slot].reset();
+  FE_API_END(ctx)
+}
+int fe_graph_loaded(fe_ctx* ctx, int slot) {
+  return ctx && slot >= 0 && slot < FE_GRAPH_SLOTS && ctx->c.graphs[slot] != nullptr;
+}
+int fe_graph_info(fe_ctx* ctx, int slot, int* n_nodes, int* n_outputs, int64_t in_dims[4], int* flags) {
+  FE_API_BEGIN(ctx)
+  GraphSlot& gs = graph_slot(ctx, slot);
+  const auto& m = gs.g.model();
+  if (n_nodes) *n_nodes = (int)m.nodes.size();
+  if (n_outputs) *n_outputs = (int)m.outputs.size();
+  if (in_dims)
+    for (int k = 0; k < 4; ++k) in_dims[k] = k < (int)m.inputs[0].dims.size() ? m.inputs[0].dims[k] : -1;
+  if (flags) *flags = (gs.g.head_has_sub() ? 1 : 0) | (gs.g.head_has_mul() ? 2 : 0);
+  FE_API_END(ctx)
+}
+static Tensor upload_nchw(Ctx& c, const float* x, int n, int ch, int h, int w, int cpad);
+int fe_graph_run(fe_ctx* ctx, int slot, const float* x, int n, int c, int h, int w, int on_device) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  GraphSlot& gs = graph_slot(ctx, slot);
+  FE_CHECK(x && n > 0 && c > 0 && h > 0 && w > 0, "bad arguments");
+  C.arena.reset();
+  const int cp = Graph::pad_channels(c);
+  Tensor xt;
+  if (on_device) {
+    xt = C.arena.tensor(n, h, w, cp);
+    launch_nchw_to_nhwc(x, xt.p, n, c, h, w, cp, C.stream);
+  } else {
+    xt = upload_nchw(C, x, n, c, h, w, cp);
+  }
+  std::vector<GraphOutput> outs;
+  gs.g.run(C, xt, c, outs);
+  gs.last.clear();
+  for (auto& o : outs) {
+    GraphSlot::Out h_out;
+    h_out.name = o.name; h_out.dims = o.dims;
+    h_out.data.resize(o.numel);
+    if (o.numel) FE_HIP(hipMemcpyAsync(h_out.data.data(), o.dev, o.numel * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+    gs.last.push_back(std::move(h_out));
+  }
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+int fe_graph_output_info(fe_ctx* ctx, int slot, int i, char* name, int name_cap, int64_t dims[6], int* rank) {
+  FE_API_BEGIN(ctx)
+  GraphSlot& gs = graph_slot(ctx, slot);
+  FE_CHECK(i >= 0 && i < (int)gs.last.size(), "output index %d out of range (%zu outputs)", i, gs.last.size());
+  const auto& o = gs.last[i];
+  FE_CHECK(o.dims.size() <= 6, "output rank %zu", o.dims.size());
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s", o.name.c_str());
+  if (rank) *rank = (int)o.dims.size();
+  if (dims) for (size_t k = 0; k < o.dims.size(); ++k) dims[k] = o.dims[k];
+  FE_API_END(ctx)
+}
+int fe_graph_output_copy(fe_ctx* ctx, int slot, int i, float* dst, size_t cap_floats) {
+  FE_API_BEGIN(ctx)
+  GraphSlot& gs = graph_slot(ctx, slot);
+  FE_CHECK(i >= 0 && i < (int)gs.last.size() && dst, "bad arguments");
+  FE_CHECK(cap_floats >= gs.last[i].data.size(), "destination holds %zu floats, output has %zu", cap_floats, gs.last[i].data.size());
+  if (!gs.last[i].data.empty()) memcpy(dst, gs.last[i].data.data(), gs.last[i].data.size() * sizeof(float));
+  FE_API_END(ctx)
 }
 
 // ---- single ops -----------------------------------------------------------------------------------
@@ -828,6 +938,172 @@ int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
     memcpy(r + 21, &host[o_emb + (size_t)i * 768], 768 * sizeof(float));
   }
   if (models_run) *models_run = (do_topiq ? 1 : 0) | (do_clip ? 2 : 0) | (do_samp ? 4 : 0);
+  FE_API_END(ctx)
+}
+
+// ---- face path (InsightFace FaceAnalysis: detection -> landmark_2d_106 -> recognition) -------------------------------
+static fe_ctx::CvResizeTab cv_resize_tab(fe_ctx* ctx, int src, int dst, bool clamp) {
+  auto key = std::make_tuple(src, dst, clamp ? 1 : 0);
+  auto it = ctx->cvresize.find(key);
+  if (it != ctx->cvresize.end()) return it->second;
+  std::vector<int> ofs;
+  std::vector<short> coef;
+  cv_resize_tables(src, dst, clamp, ofs, coef);
+  fe_ctx::CvResizeTab t{};
+  FE_HIP(hipMalloc((void**)&t.ofs, ofs.size() * sizeof(int)));
+  ctx->misc_allocs.push_back(t.ofs);
+  FE_HIP(hipMalloc((void**)&t.coef, coef.size() * sizeof(short)));
+  ctx->misc_allocs.push_back(t.coef);
+  FE_HIP(hipMemcpy(t.ofs, ofs.data(), ofs.size() * sizeof(int), hipMemcpyHostToDevice));
+  FE_HIP(hipMemcpy(t.coef, coef.data(), coef.size() * sizeof(short), hipMemcpyHostToDevice));
+  return ctx->cvresize[key] = t;
+}
+
+int fe_face_detect(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, int det_h, int det_w, float thresh,
+                   int max_cand, float* cand, int* counts, float* det_scale_out) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  GraphSlot& gs = graph_slot(ctx, FE_GRAPH_FACE_DET);
+  FE_CHECK(bgr && cand && counts && n > 0 && h > 0 && w > 0 && det_h >= 32 && det_w >= 32 && det_h % 32 == 0 && det_w % 32 == 0 &&
+               max_cand > 0, "bad arguments");
+  // SCRFD.detect: keep the aspect ratio, fill the top-left of the det canvas (insightface model_zoo/scrfd.py [DEP-KNOWLEDGE])
+  const float im_ratio = (float)h / (float)w, model_ratio = (float)det_h / (float)det_w;
+  int new_h, new_w;
+  if (im_ratio > model_ratio) { new_h = det_h; new_w = (int)((float)new_h / im_ratio); }
+  else { new_w = det_w; new_h = (int)((float)new_w * im_ratio); }
+  FE_CHECK(new_h > 0 && new_w > 0, "image aspect ratio leaves an empty detector input");
+  const float det_scale = (float)new_h / (float)h;
+  if (det_scale_out) *det_scale_out = det_scale;
+  const bool area2 = (h == 2 * new_h && w == 2 * new_w);
+  const bool copy_only = (h == new_h && w == new_w);
+  auto tx = cv_resize_tab(ctx, w, new_w, true), ty = cv_resize_tab(ctx, h, new_h, false);
+
+  const size_t no = gs.g.model().outputs.size();
+  int fmc, K = 0, A;
+  if (no == 6) { fmc = 3; A = 2; }
+  else if (no == 9) { fmc = 3; A = 2; K = 5; }
+  else if (no == 10) { fmc = 5; A = 1; }
+  else if (no == 15) { fmc = 5; A = 1; K = 5; }
+  else FE_CHECK(false, "detector graph has %zu outputs; SCRFD layouts have 6, 9, 10 or 15", no);
+  static const int kStrides3[3] = {8, 16, 32}, kStrides5[5] = {8, 16, 32, 64, 128};
+  const int* strides = fmc == 3 ? kStrides3 : kStrides5;
+
+  const size_t per = (size_t)h * w * 3;
+  float* d_cand = ctx->out_buf((size_t)n * max_cand * 16 + (size_t)n + 16);
+  int* d_counts = (int*)(d_cand + (size_t)n * max_cand * 16);
+  FE_HIP(hipMemsetAsync(d_counts, 0, (size_t)n * sizeof(int), C.stream));
+  ImageStager st(ctx, bgr, n, per, ctx->microbatch, on_device);
+  for (int k = 0; k < st.chunks(); ++k) {
+    const int i0 = k * ctx->microbatch, nb = st.count(k);
+    C.arena.reset();
+    const uint8_t* d_in = st.get(k);
+    uint8_t* canvas = (uint8_t*)C.arena.alloc((size_t)nb * det_h * det_w * 3);
+    FE_HIP(hipMemsetAsync(canvas, 0, (size_t)nb * det_h * det_w * 3, C.stream));
+    if (copy_only) {
+      for (int b = 0; b < nb; ++b)
+        FE_HIP(hipMemcpy2DAsync(canvas + (size_t)b * det_h * det_w * 3, (size_t)det_w * 3, d_in + (size_t)b * per, (size_t)w * 3, (size_t)w * 3, h,
+                                hipMemcpyDeviceToDevice, C.stream));
+    } else {
+      launch_cv_resize_linear(d_in, nb, h, w, canvas, det_h, det_w, new_h, new_w, tx.ofs, tx.coef, ty.ofs, ty.coef, area2 ? 1 : 0, C.stream);
+    }
+    st.done(k);
+    Tensor x = C.arena.tensor(nb, det_h, det_w, 4);
+    launch_u8_blob(canvas, x.p, (size_t)nb * det_h * det_w, 127.5f, 1.0f / 128.0f, 1, C.stream);
+    std::vector<GraphOutput> outs;
+    gs.g.run(C, x, 3, outs);
+    for (int l = 0; l < fmc; ++l) {
+      const int s = strides[l], fh = det_h / s, fw = det_w / s;
+      const size_t rows = (size_t)nb * fh * fw * A;
+      FE_CHECK(outs[l].numel == rows && outs[l + fmc].numel == rows * 4 && (!K || outs[l + 2 * fmc].numel == rows * 2 * K),
+               "detector output %d has %zu values, expected %zu rows for stride %d", l, outs[l].numel, rows, s);
+      launch_scrfd_decode(outs[l].dev, outs[l + fmc].dev, K ? outs[l + 2 * fmc].dev : nullptr, nb, fh, fw, A, K, s, thresh, det_scale, l,
+                          d_cand + (size_t)i0 * max_cand * 16, d_counts + i0, max_cand, C.stream);
+    }
+  }
+  FE_HIP(hipMemcpyAsync(counts, d_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipMemcpyAsync(cand, d_cand, (size_t)n * max_cand * 16 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+int fe_face_crops_run(fe_ctx* ctx, int slot, const uint8_t* bgr, int n, int h, int w, int on_device, int m, const int* img_index,
+                      const double* M, int size, float mean, float scale, int swap_rb, float* out, int out_dim, uint8_t* crops_out) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(bgr && n > 0 && h > 0 && w > 0 && m >= 0 && size > 0 && (m == 0 || (img_index && M)), "bad arguments");
+  FE_CHECK(out || crops_out, "nothing to compute: both outputs are null");
+  GraphSlot* gs = out ? &graph_slot(ctx, slot) : nullptr;
+  if (m == 0) return FE_OK;
+  if (!ctx->warp_wtab) {
+    std::vector<short> wt;
+    cv_warp_weight_table(wt);
+    FE_HIP(hipMalloc((void**)&ctx->warp_wtab, wt.size() * sizeof(short)));
+    ctx->misc_allocs.push_back(ctx->warp_wtab);
+    FE_HIP(hipMemcpy(ctx->warp_wtab, wt.data(), wt.size() * sizeof(short), hipMemcpyHostToDevice));
+  }
+  // cv::warpAffine inverts the forward matrix in double before walking the destination
+  std::vector<double> inv((size_t)m * 6);
+  for (int f = 0; f < m; ++f) {
+    FE_CHECK(img_index[f] >= 0 && img_index[f] < n, "crop %d refers to image %d of %d", f, img_index[f], n);
+    const double* a = M + (size_t)f * 6;
+    double D = a[0] * a[4] - a[1] * a[3];
+    D = D != 0.0 ? 1.0 / D : 0.0;
+    const double A11 = a[4] * D, A22 = a[0] * D;
+    double* o = &inv[(size_t)f * 6];
+    o[0] = A11; o[1] = a[1] * (-D); o[3] = a[3] * (-D); o[4] = A22;
+    o[2] = -o[0] * a[2] - o[1] * a[5];
+    o[5] = -o[3] * a[2] - o[4] * a[5];
+  }
+  C.arena.reset();
+  const uint8_t* d_img = bgr;
+  if (!on_device) {
+    uint8_t* d = (uint8_t*)C.arena.alloc((size_t)n * h * w * 3);
+    FE_HIP(hipMemcpyAsync(d, bgr, (size_t)n * h * w * 3, hipMemcpyHostToDevice, C.stream));
+    d_img = d;
+  }
+  double* d_inv = (double*)C.arena.alloc(inv.size() * sizeof(double));
+  int* d_idx = (int*)C.arena.alloc((size_t)m * sizeof(int));
+  FE_HIP(hipMemcpyAsync(d_inv, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice, C.stream));
+  FE_HIP(hipMemcpyAsync(d_idx, img_index, (size_t)m * sizeof(int), hipMemcpyHostToDevice, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));   // inv is a local; the copies above must finish before it goes away
+  float* d_out = out ? ctx->out_buf((size_t)m * out_dim) : nullptr;
+  const size_t base = C.arena.mark();
+  const int mb = std::max(1, ctx->microbatch * 2);
+  for (int f0 = 0; f0 < m; f0 += mb) {
+    const int fb = std::min(mb, m - f0);
+    C.arena.rewind(base);
+    uint8_t* crops = (uint8_t*)C.arena.alloc((size_t)fb * size * size * 3);
+    launch_warp_affine(d_img, h, w, d_idx + f0, d_inv + (size_t)f0 * 6, fb, size, ctx->warp_wtab, crops, C.stream);
+    if (crops_out)
+      FE_HIP(hipMemcpyAsync(crops_out + (size_t)f0 * size * size * 3, crops, (size_t)fb * size * size * 3, hipMemcpyDeviceToHost, C.stream));
+    if (out) {
+      Tensor x = C.arena.tensor(fb, size, size, 4);
+      launch_u8_blob(crops, x.p, (size_t)fb * size * size, mean, scale, swap_rb, C.stream);
+      std::vector<GraphOutput> outs;
+      gs->g.run(C, x, 3, outs);
+      FE_CHECK(outs[0].numel == (size_t)fb * out_dim, "graph output has %zu values for %d crops, expected %d each", outs[0].numel, fb, out_dim);
+      FE_HIP(hipMemcpyAsync(d_out + (size_t)f0 * out_dim, outs[0].dev, outs[0].numel * sizeof(float), hipMemcpyDeviceToDevice, C.stream));
+    }
+  }
+  if (out) FE_HIP(hipMemcpyAsync(out, d_out, (size_t)m * out_dim * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+/* cv2.resize(img, (ow, oh)) INTER_LINEAR on uint8 HWC images (restated fixed-point path); exposed for the parity tests */
+int fe_cv_resize_linear_u8(fe_ctx* ctx, const uint8_t* src, int n, int h, int w, int oh, int ow, uint8_t* dst) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(src && dst && n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "bad arguments");
+  C.arena.reset();
+  uint8_t* d_src = (uint8_t*)C.arena.alloc((size_t)n * h * w * 3);
+  uint8_t* d_dst = (uint8_t*)C.arena.alloc((size_t)n * oh * ow * 3);
+  FE_HIP(hipMemcpyAsync(d_src, src, (size_t)n * h * w * 3, hipMemcpyHostToDevice, C.stream));
+  auto tx = cv_resize_tab(ctx, w, ow, true), ty = cv_resize_tab(ctx, h, oh, false);
+  if (h == oh && w == ow) FE_HIP(hipMemcpyAsync(d_dst, d_src, (size_t)n * h * w * 3, hipMemcpyDeviceToDevice, C.stream));
+  else launch_cv_resize_linear(d_src, n, h, w, d_dst, oh, ow, oh, ow, tx.ofs, tx.coef, ty.ofs, ty.coef, (h == 2 * oh && w == 2 * ow) ? 1 : 0, C.stream);
+  FE_HIP(hipMemcpyAsync(dst, d_dst, (size_t)n * oh * ow * 3, hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
   FE_API_END(ctx)
 }
 

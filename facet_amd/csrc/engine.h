@@ -45,6 +45,8 @@ struct LayerNormW {
 };
 
 // Build helpers ------------------------------------------------------------------------------------
+// packs an OIHW (or [out][in]) weight for the conv kernels; scale/shift are per-Cout epilogue vectors (nullable)
+ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>* scale, const std::vector<float>* shift);
 // conv (OIHW) with optional bias and optional eval-mode BatchNorm folded into per-channel scale/shift.
 ConvW build_conv(DeviceWeights& dw, const WeightStore& ws, const std::string& conv_prefix,
                  const std::string& bn_prefix, bool conv_bias, float bn_eps = 1e-5f);
@@ -107,6 +109,9 @@ void build_resize_coeffs(int in_size, int out_size, int filter, ResizeCoeffs& rc
 void resize_u8(Ctx& c, const uint8_t* d_src, int n, int h, int w, int oh, int ow, int filter, int y0, int ch, int x0,
                int cw, uint8_t* d_dst);
 
+class Graph;   // onnx_graph.h
+struct GraphSlot;
+
 struct OpTiming { std::string name; double flops; double bytes; float ms; };
 
 struct Ctx {
@@ -129,6 +134,7 @@ struct Ctx {
   std::unique_ptr<struct ClipModel> clip;
   std::unique_ptr<struct AestheticModel> aesthetic;
   std::unique_ptr<struct ClipTextModel> clip_text;
+  std::unique_ptr<GraphSlot> graphs[8];   // ONNX graphs (face detector / landmarks / recognition, ...)
   ~Ctx();
 };
 

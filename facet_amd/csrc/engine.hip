@@ -1,5 +1,6 @@
 // Engine runtime: weight packing, conv/linear wrappers and the ResNet graphs.
 #include "engine.h"
+#include "onnx_graph.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -38,8 +39,7 @@ Ctx::~Ctx() {
   if (stream) (void)hipStreamDestroy(stream);
 }
 
-static ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>* scale,
-                       const std::vector<float>* shift) {
+ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>* scale, const std::vector<float>* shift) {
   FE_CHECK(w.shape.size() == 4 || w.shape.size() == 2, "conv weight rank %zu", w.shape.size());
   ConvW c;
   c.Cout = (int)w.shape[0];
@@ -144,7 +144,8 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
   FE_CHECK(y.c == w.Cout && y.n == x.n, "conv: output view mismatch (c=%d Cout=%d)", y.c, w.Cout);
   ConvParams p{};
   p.x = x.p; p.ldx = x.ld;
-  p.w = w.w; p.scale = w.scale; p.shift = w.shift;
+  p.w = w.w; p.scale = w.scale; p.shift = w.shift; p.slope = w.slope;
+  FE_CHECK(o.act != ACT_PRELU || w.slope, "conv: PReLU without slopes");
   if (o.res) {
     FE_CHECK(o.res->c == y.c && o.res->pixels() == y.pixels(), "conv: residual shape mismatch");
     p.res = o.res->p; p.ldr = o.res->ld;
@@ -164,7 +165,7 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
   FE_CHECK(y.pixels() < (1ull << 31), "conv: M too large");
   p.act = o.act; p.res_after_act = o.res_after_act;
   p.variant = c.force_variant;
-  if (w.wtap && o.sh == 1 && o.sw == 1 && !o.res && !o.gate && p.variant == 0 && y.h == x.h && y.w == x.w) {
+  if (w.wtap && o.act != ACT_PRELU && o.sh == 1 && o.sw == 1 && !o.res && !o.gate && p.variant == 0 && y.h == x.h && y.w == x.w) {
     // narrow spatial conv (Cout <= 2): 1x1 conv to per-tap partials on the matrix cores + a gather-sum pass
     const int T = w.KH * w.KW * w.Cout, Tp = (T + 3) & ~3;
     const size_t mark = c.arena.mark();
@@ -278,7 +279,7 @@ namespace fe {
 
 void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act,
                     const float* res, int ldr) {
-  if (M <= 32 && !res && c.force_variant == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w.w) & 15) == 0) {
+  if (M <= 32 && !res && act != ACT_PRELU && c.force_variant == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w.w) & 15) == 0) {
     // per-image vectors: stream the weight matrix once instead of idling 255 CUs behind one 128-row tile
     launch_gemm_skinny(x, ldx, w.w, w.Kp, w.scale, w.shift, y, ldy, M, w.Cout, w.K, act, c.stream);
     c.flops_accum += 2.0 * M * (double)w.Cin * w.Cout;

@@ -40,7 +40,7 @@ struct Error : std::runtime_error {
   } while (0)
 
 // Activation codes shared by the GEMM/conv epilogue.
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_PRELU = 4 };  // PRELU: per-channel slope
 
 // A view of an NHWC fp32 activation in HBM. `ld` is the channel stride of one pixel
 // (>= c) so a view can be a channel slice of a wider (concat) buffer.
@@ -104,6 +104,7 @@ struct ConvParams {
   const float* w;                   // packed [Cout][Kp], k = (kh, kw, ci) with ci fastest, zero padded to Kp
   const float* scale;               // per-Cout multiply (nullable => 1)
   const float* shift;               // per-Cout add (nullable => 0)
+  const float* slope;               // per-Cout negative slope, ACT_PRELU only
   const float* res; int ldr;        // residual view, same N,Ho,Wo,Cout (nullable)
   const float* gate; int ldg;       // multiplicative gate, ldg==... (nullable); gate_c1: single channel broadcast
   float* y; int ldy;                // output NHWC view
@@ -127,6 +128,7 @@ struct ConvW {
   float* w = nullptr;      // [Cout][Kp]
   float* scale = nullptr;  // [Cout] or null
   float* shift = nullptr;  // [Cout] or null
+  float* slope = nullptr;  // [Cout] PReLU slopes or null
   int Cout = 0, Cin = 0, CinPad = 0, KH = 1, KW = 1, K = 0, Kp = 0;
   // Cout <= 2 spatial kernels also carry a tap-decomposed form: rows (tap, co) of a 1x1 conv [KH*KW*Cout][KpT]
   float* wtap = nullptr;
@@ -187,5 +189,33 @@ void launch_softmax_rows(float* x, int ld, int rows, int d, hipStream_t s);
 void launch_softmax_rows_pad(float* x, int ld, int rows, int d, hipStream_t s);
 // y[rows][d] += pos[(row % L)][d]
 void launch_add_rows_bcast(float* y, int ldy, const float* pos, int rows, int L, int d, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Graph-runtime kernels (kernels_graph.hip); channel counts are multiples of 4
+// ---------------------------------------------------------------------------------------
+void launch_affine_act(const Tensor& x, const Tensor& y, const float* scale, const float* shift, int act, const float* slope,
+                       hipStream_t s);
+// op: 0 add, 1 sub, 2 mul, 3 div
+void launch_binary(const Tensor& a, const Tensor& b, const Tensor& y, int op, int act, hipStream_t s);
+// dst dense [dims0..5] row-major; element (i0..i5) read from src[sum i_k * sstr_k]
+void launch_gather_strided(const float* src, float* dst, const long long dims[6], const long long sstr[6], hipStream_t s);
+void launch_nearest(const Tensor& x, const Tensor& y, hipStream_t s);
+void launch_avgpool(const Tensor& x, const Tensor& y, int k, int stride, int pad, int include_pad, hipStream_t s);
+// wt: [kh*kw][C] tap-major depthwise weights
+void launch_dwconv(const Tensor& x, const Tensor& y, const float* wt, int kh, int kw, int sh, int sw, int ph, int pw,
+                   const float* scale, const float* shift, int act, const float* slope, const Tensor* res, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Face-path pixel kernels (kernels_face.hip)
+// ---------------------------------------------------------------------------------------
+void launch_cv_resize_linear(const uint8_t* src, int n, int h, int w, uint8_t* dst, int ch, int cw, int nh, int nw, const int* xofs,
+                             const short* ialpha, const int* yofs, const short* ibeta, int area2, hipStream_t s);
+void launch_warp_affine(const uint8_t* src, int h, int w, const int* img_of, const double* Minv, int m, int S, const short* wtab,
+                        uint8_t* dst, hipStream_t s);
+void launch_u8_blob(const uint8_t* src, float* dst, size_t pixels, float mean, float scale, int swap_rb, hipStream_t s);
+void launch_scrfd_decode(const float* scores, const float* bbox, const float* kps, int n, int fh, int fw, int A, int K, int stride,
+                         float thresh, float det_scale, int level, float* cand, int* counts, int max_cand, hipStream_t s);
+void cv_resize_tables(int src, int dst, bool clamp_fx, std::vector<int>& ofs, std::vector<short>& coef);
+void cv_warp_weight_table(std::vector<short>& wtab);
 
 }  // namespace fe

@@ -233,7 +233,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, const int
         float4 v = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc]);
         v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
         if (p.res && !p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
-        v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+        if (p.act == ACT_PRELU) {
+          const float4 sl = *reinterpret_cast<const float4*>(p.slope + colc);
+          v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
+          v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+        } else {
+          v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+        }
         if (p.res && p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
         if (p.gate) { v.x *= gv[it].x; v.y *= gv[it].y; v.z *= gv[it].z; v.w *= gv[it].w; }
         if (cok && m < p.M) *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + colb) = v;
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, const int
         if (cok && m < p.M) {
           float v = acc[i][j][e] * sc + sf;
           if (p.res && !p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
-          v = apply_act(v, p.act);
+          v = p.act == ACT_PRELU ? (v > 0.f ? v : v * p.slope[col]) : apply_act(v, p.act);
           if (p.res && p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
           if (p.gate) v *= p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
           p.y[(size_t)m * p.ldy + col] = v;
@@ -320,7 +326,9 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
   // forced variants (tests / tools): 1-7 register-staged tiles, 11-18 LDS-DMA tiles, 21/22 lean LDS-DMA tiles
   if (q.variant > 10 && q.variant < 40) { launch_conv_dma(q, q.variant > 20 ? q.variant : q.variant - 10, s); return; }
   if (q.variant > 0) { launch_forced(q, s); return; }
-  if (p.Cout <= 4 && q.batch <= 1 && !p.gate && q.variant == 0) { launch_conv_narrow(q, s); return; }
+  // the narrow kernel reads weights in plain (tap, ci) order; pack_conv blocks K by 16 channels once Cin % 16 == 0 and there
+  // is more than one tap, so those go to the matrix-core path below (256x32 tile)
+  if (p.Cout <= 4 && q.batch <= 1 && !p.gate && q.variant == 0 && (p.Cin % 16 != 0 || p.KH * p.KW == 1)) { launch_conv_narrow(q, s); return; }
   static const bool no_dma = getenv("FE_NO_DMA") != nullptr;
   const unsigned long long xspan = ((unsigned long long)p.N * p.H * p.W - 1) * (unsigned long long)p.ldx * 4 + (unsigned long long)p.Cin * 4;
   const unsigned long long wspan = ((unsigned long long)p.Cout - 1) * (unsigned long long)q.ldw * 4 + (unsigned long long)p.Kp * 4;

@@ -29,6 +29,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // MODE 0: 3-slab ring + double-buffered fragments (3 waves/SIMD for 64x64 wave tiles).
 // MODE 1: lean - 2 slabs, one fragment set, register budget of 128 so FOUR waves/SIMD are resident.
+// MODE 2: MODE 0 with a PReLU epilogue (per-channel slopes); separate instantiation so the hot tiles keep their registers.
 template <int WGM, int WGN, int TM, int TN, int MODE = 0>
 __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4)))) void conv_dma_kernel(ConvParams p, const int ntiles) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = 16;
@@ -272,7 +273,13 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
         float4 v = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc]);
         v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
         if (p.res && !p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
-        v.x = apply_act_d(v.x, p.act); v.y = apply_act_d(v.y, p.act); v.z = apply_act_d(v.z, p.act); v.w = apply_act_d(v.w, p.act);
+        if constexpr (MODE == 2) {
+          const float4 sl = *reinterpret_cast<const float4*>(p.slope + colc);
+          v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
+          v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+        } else {
+          v.x = apply_act_d(v.x, p.act); v.y = apply_act_d(v.y, p.act); v.z = apply_act_d(v.z, p.act); v.w = apply_act_d(v.w, p.act);
+        }
         if (p.res && p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
         if (p.gate) { v.x *= gv[it].x; v.y *= gv[it].y; v.z *= gv[it].z; v.w *= gv[it].w; }
         if (cok && m < p.M) *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + colb) = v;
@@ -295,7 +302,8 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
         if (cok && m < p.M) {
           float v = acc[i][j][e] * sc + sf;
           if (p.res && !p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
-          v = apply_act_d(v, p.act);
+          if constexpr (MODE == 2) v = v > 0.f ? v : v * p.slope[col];
+          else v = apply_act_d(v, p.act);
           if (p.res && p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
           if (p.gate) v *= p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
           p.y[(size_t)m * p.ldy + col] = v;
@@ -332,6 +340,16 @@ void launch_conv_dma(const ConvParams& p0, int tile, hipStream_t s) {
   p.buf_ok = !no_buf && xs < 0xFFFFFF00ull && ws < 0xFFFFFF00ull;
   FE_CHECK(p.buf_ok, "conv_dma: operand spans exceed 32-bit buffer addressing (caller must use the register-staged kernel)");
   p.x_span = (unsigned)xs; p.w_span = (unsigned)ws;
+  if (p.act == ACT_PRELU) {
+    FE_CHECK(p.slope, "conv_dma: PReLU without slopes");
+    switch (tile) {
+      case 3: launch_dma_variant<4, 1, 2, 1, 2>(p, s); break;
+      case 4: launch_dma_variant<2, 2, 1, 1, 2>(p, s); break;
+      case 2: case 22: case 7: launch_dma_variant<2, 2, 2, 1, 2>(p, s); break;
+      default: launch_dma_variant<2, 2, 2, 2, 2>(p, s); break;
+    }
+    return;
+  }
   switch (tile) {
     case 1: launch_dma_variant<2, 2, 2, 2>(p, s); break;
     case 21: launch_dma_variant<2, 2, 2, 2, 1>(p, s); break;   // lean 128x128, 4 waves/SIMD

@@ -255,6 +255,7 @@ __global__ void conv_narrow_kernel(const ConvParams p) {
         if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
         else if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+        else if (p.act == ACT_PRELU) v = v > 0.f ? v : v * p.slope[o];
         if (p.res && p.res_after_act) v += p.res[(size_t)m * p.ldr + o];
         p.y[(size_t)m * p.ldy + o] = v;
       }

@@ -1,15 +1,217 @@
-"""Interface mirror of reference analyzers/face.py `FaceAnalyzer` — WITHOUT a detector.
+"""Drop-in for reference analyzers/face.py `FaceAnalyzer`, with InsightFace's FaceAnalysis pipeline served by libfacet_engine.so.
 
-InsightFace buffalo_l (SCRFD-10GF, 2d106det, ArcFace-R50) is served to the reference by onnxruntime from ONNX files
-that are not available offline, so the engine has no face models yet.
-This mirror keeps the call surface the orchestrator depends on, with the reference's own "unavailable" behaviour:
-  FaceAnalyzer(device, min_confidence, min_face_size, thumbnail_size, thumbnail_quality, blink_ear_threshold,
-               min_faces_for_group); .available; .analyze_faces(BGR ndarray) -> dict; static compute_avg_ear(landmarks).
-`available` is False, so analyze_faces returns the zeros dict exactly as the reference does when InsightFace fails
-to import (face.py:90-97); the EAR helpers (pure arithmetic, face.py:236-270) are complete because
-processing/scorer.py:1405 calls FaceAnalyzer.compute_avg_ear on stored landmarks.
+Reference behaviour mirrored (analyzers/face.py): constructor arguments and attributes (:15-29), `.available` (False with the
+"InsightFace not available: ..." message when the models cannot be loaded, :39-40), `analyze_faces(BGR ndarray) -> dict` with the
+same keys, filtering (confidence, min size :101-122), aggregation (:134-234), EAR helpers (:236-270) and crop sharpness (:272-279).
+
+What runs where:
+  GPU (engine): SCRFD preprocessing (cv2.resize + canvas + blob), detector graph, threshold/decode; for ALL faces of a batch
+      in one call each: similarity-warped 112x112 crops + ArcFace graph, 192x192 crops + 2d106 landmark graph
+      (fe_face_detect / fe_face_crops_run, include/facet_engine.h). The reference runs these per image and per face.
+  host (here): sort + NMS over the few candidates, 5-point similarity estimate, landmark back-projection, the reference's own
+      post-processing (gray / Laplacian variance on small ROIs, EAR, aggregation) and JPEG thumbnails.
+The three networks are the reference's own files: <root>/models/buffalo_l/{det_10g,2d106det,w600k_r50}.onnx (insightface's
+layout, root='~/.insightface' at face.py:34), parsed by the engine's ONNX runtime; `models=` passes bytes directly (tests use
+facet_amd.synthetic_onnx). insightface internals follow the published package [DEP-KNOWLEDGE]; cv2 is not importable here, so
+gray/Laplacian are restated in numpy and thumbnails are encoded with Pillow (not bit-identical to cv2.imencode).
 """
+import io
+import os
+
 import numpy as np
+
+from ._lib import Engine, EngineError, FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC
+
+ARCFACE_DST = np.array([[38.2946, 51.6963], [73.5318, 51.5014], [56.0252, 71.7366], [41.5493, 92.3655], [70.7299, 92.2041]],
+                       dtype=np.float32)
+BUFFALO_L = {"det": "det_10g.onnx", "lmk": "2d106det.onnx", "rec": "w600k_r50.onnx"}
+
+
+class Face(dict):
+    """insightface.app.common.Face: a dict whose keys read as attributes (missing -> None)."""
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return self.get(name)
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+
+def similarity_from_5pts(src, dst):
+    """Least-squares similarity (rotation, uniform scale, translation) src -> dst, the transform skimage's
+    SimilarityTransform.estimate (Umeyama) yields for 2-D points. Closed form: the best proper rotation maximises
+    trace(R^T A), giving angle atan2(A10 - A01, A00 + A11) and scale |.| / var(src)."""
+    src = np.asarray(src, np.float64)
+    dst = np.asarray(dst, np.float64)
+    sm, dm = src.mean(axis=0), dst.mean(axis=0)
+    sd, dd = src - sm, dst - dm
+    A = dd.T @ sd / src.shape[0]
+    p, q = A[0, 0] + A[1, 1], A[1, 0] - A[0, 1]
+    r = np.hypot(p, q)
+    if r == 0:
+        return np.full((2, 3), np.nan)
+    c, s = p / r, q / r
+    scale = r / sd.var(axis=0).sum()
+    R = np.array([[c, -s], [s, c]]) * scale
+    t = dm - R @ sm
+    return np.array([[R[0, 0], R[0, 1], t[0]], [R[1, 0], R[1, 1], t[1]]], np.float64)
+
+
+def invert_affine(M):
+    """cv2.invertAffineTransform for [m,2,3] matrices."""
+    M = np.asarray(M, np.float64)
+    D = M[:, 0, 0] * M[:, 1, 1] - M[:, 0, 1] * M[:, 1, 0]
+    D = np.where(D != 0, 1.0 / np.where(D != 0, D, 1.0), 0.0)
+    A11, A22, A12, A21 = M[:, 1, 1] * D, M[:, 0, 0] * D, -M[:, 0, 1] * D, -M[:, 1, 0] * D
+    out = np.empty_like(M)
+    out[:, 0, 0], out[:, 0, 1], out[:, 0, 2] = A11, A12, -A11 * M[:, 0, 2] - A12 * M[:, 1, 2]
+    out[:, 1, 0], out[:, 1, 1], out[:, 1, 2] = A21, A22, -A21 * M[:, 0, 2] - A22 * M[:, 1, 2]
+    return out
+
+
+def nms(dets, thresh=0.4):
+    """insightface SCRFD.nms on score-sorted rows [x1,y1,x2,y2,score]; returns kept row indices."""
+    if dets.shape[0] == 0:
+        return []
+    x1, y1, x2, y2 = dets[:, 0], dets[:, 1], dets[:, 2], dets[:, 3]
+    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
+    order = dets[:, 4].argsort()[::-1]
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(int(i))
+        rest = order[1:]
+        w = np.maximum(0.0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + 1)
+        h = np.maximum(0.0, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + 1)
+        inter = w * h
+        ovr = inter / (areas[i] + areas[rest] - inter)
+        order = rest[ovr <= thresh]
+    return keep
+
+
+def bgr2gray(img):
+    """cv2.cvtColor(img, COLOR_BGR2GRAY) for uint8: 14-bit fixed point (R 4899, G 9617, B 1868)."""
+    a = img.astype(np.int32)
+    return ((a[..., 0] * 1868 + a[..., 1] * 9617 + a[..., 2] * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def laplacian_var(gray):
+    """cv2.Laplacian(gray, cv2.CV_64F).var(): aperture 1 (4-neighbour), BORDER_REFLECT_101."""
+    if gray.size == 0:
+        return 0.0
+    g = gray.astype(np.float64)
+    p = np.pad(g, 1, mode="reflect") if min(g.shape) > 1 else np.pad(g, 1, mode="edge")
+    lap = p[:-2, 1:-1] + p[2:, 1:-1] + p[1:-1, :-2] + p[1:-1, 2:] - 4.0 * g
+    return float(lap.var())
+
+
+class FaceEngine:
+    """insightface.app.FaceAnalysis for batches: detection -> landmark_2d_106 -> recognition on the engine."""
+
+    def __init__(self, engine, models, det_size=(640, 640), det_thresh=0.5, nms_thresh=0.4, max_candidates=1024):
+        self.engine = engine
+        self.det_size, self.det_thresh, self.nms_thresh, self.max_candidates = det_size, det_thresh, nms_thresh, max_candidates
+        if "det" not in models:
+            raise EngineError("face models: a detection model is required")     # FaceAnalysis asserts 'detection' in models
+        self.has = {k: k in models for k in ("det", "lmk", "rec")}
+        for key, slot in (("det", FE_GRAPH_FACE_DET), ("lmk", FE_GRAPH_FACE_LMK), ("rec", FE_GRAPH_FACE_REC)):
+            if key in models:
+                engine.graph_load(slot, models[key])
+        # input normalisation as insightface picks it: Sub/Mul nodes at the head of the graph -> the model normalises itself
+        self.norm = {}
+        for key, slot, default_std in (("lmk", FE_GRAPH_FACE_LMK, 128.0), ("rec", FE_GRAPH_FACE_REC, 127.5)):
+            if self.has[key]:
+                info = engine.graph_info(slot)
+                self.norm[key] = (0.0, 1.0) if (info["has_sub"] and info["has_mul"]) else (127.5, default_std)
+                self.norm[key + "_size"] = int(info["input_dims"][2]) if info["input_dims"][2] > 0 else (192 if key == "lmk" else 112)
+
+    def unload(self):
+        for slot in (FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC):
+            if self.engine.graph_loaded(slot):
+                self.engine.graph_unload(slot)
+
+    def detect(self, images):
+        """images: BGR uint8 [n,h,w,3] -> per image (det [k,5] float32 sorted by score, kps [k,5,2] float32)."""
+        cand, counts, _ = self.engine.face_detect(images, self.det_size, self.det_thresh, self.max_candidates)
+        out = []
+        for i in range(cand.shape[0]):
+            k = int(min(counts[i], self.max_candidates))
+            c = cand[i, :k]
+            # SCRFD.detect sorts all levels by score before NMS; ties broken by (level, position) to be deterministic
+            order = np.lexsort((c[:, 2], c[:, 1], c[:, 15], -c[:, 0]))
+            c = c[order]
+            pre = np.concatenate([c[:, 1:5], c[:, 0:1]], axis=1).astype(np.float32)
+            keep = nms(pre, self.nms_thresh)
+            out.append((pre[keep], c[keep, 5:15].reshape(-1, 5, 2).astype(np.float32)))
+        return out
+
+    def get_batch(self, images):
+        """FaceAnalysis.get for every image of a same-sized BGR batch; returns list (per image) of list[Face]."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        n, h, w, _ = images.shape
+        e = self.engine
+        d = e.dev_alloc(images.nbytes)
+        try:
+            e.h2d(d, images)
+            dev = (d, n, h, w)
+            dets = self.detect(dev)
+            img_idx = np.concatenate([np.full(det.shape[0], i, np.int32) for i, (det, _) in enumerate(dets)]) if dets else np.zeros(0, np.int32)
+            boxes = np.concatenate([det for det, _ in dets]) if dets else np.zeros((0, 5), np.float32)
+            kpss = np.concatenate([k for _, k in dets]) if dets else np.zeros((0, 5, 2), np.float32)
+            m = boxes.shape[0]
+            lmk = emb = None
+            if m and self.has["lmk"]:
+                S = self.norm["lmk_size"]
+                b = boxes[:, :4].astype(np.float64)
+                bw, bh = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+                cx, cy = (b[:, 2] + b[:, 0]) / 2, (b[:, 3] + b[:, 1]) / 2
+                sc = S / (np.maximum(bw, bh) * 1.5)
+                M = np.zeros((m, 2, 3), np.float64)
+                M[:, 0, 0] = M[:, 1, 1] = sc
+                M[:, 0, 2] = -cx * sc + S / 2
+                M[:, 1, 2] = -cy * sc + S / 2
+                mean, std = self.norm["lmk"]
+                pred, _ = e.face_crops_run(FE_GRAPH_FACE_LMK, dev, img_idx, M, S, mean, 1.0 / std, True, out_dim=212)
+                pred = pred.reshape(m, -1, 2)
+                pred = (pred + np.float32(1)) * np.float32(S // 2)
+                IM = invert_affine(M)
+                hom = np.concatenate([pred, np.ones((m, pred.shape[1], 1), np.float32)], axis=2).astype(np.float64)
+                lmk = np.einsum('mij,mkj->mki', IM, hom).astype(np.float32)
+            if m and self.has["rec"]:
+                S = self.norm["rec_size"]
+                dst = ARCFACE_DST.astype(np.float64) * (float(S) / 112.0)
+                M = np.stack([similarity_from_5pts(kpss[f], dst) for f in range(m)])
+                mean, std = self.norm["rec"]
+                emb, _ = e.face_crops_run(FE_GRAPH_FACE_REC, dev, img_idx, M, S, mean, 1.0 / std, True, out_dim=512)
+        finally:
+            e.dev_free(d)
+        faces = [[] for _ in range(n)]
+        for f in range(m):
+            face = Face(bbox=boxes[f, :4], kps=kpss[f], det_score=boxes[f, 4])
+            if lmk is not None:
+                face['landmark_2d_106'] = lmk[f]
+            if emb is not None:
+                face['embedding'] = emb[f]
+            faces[int(img_idx[f])].append(face)
+        return faces
+
+    def get(self, img):
+        return self.get_batch(np.asarray(img)[None])[0]
+
+
+def _load_buffalo_l(root):
+    d = os.path.join(os.path.expanduser(root), 'models', 'buffalo_l')
+    models = {}
+    for key, fn in BUFFALO_L.items():
+        p = os.path.join(d, fn)
+        if os.path.exists(p):
+            with open(p, 'rb') as f:
+                models[key] = f.read()
+    if "det" not in models:
+        raise FileNotFoundError(f"{os.path.join(d, BUFFALO_L['det'])} not found (the engine does not download models)")
+    return models
 
 
 class FaceAnalyzer:
@@ -18,7 +220,7 @@ class FaceAnalyzer:
     RIGHT_EYE_INDICES = [89, 93, 91, 92, 95, 94]
 
     def __init__(self, device='cuda', min_confidence=0.7, min_face_size=30, thumbnail_size=128, thumbnail_quality=85,
-                 blink_ear_threshold=0.21, min_faces_for_group=4):
+                 blink_ear_threshold=0.21, min_faces_for_group=4, engine=None, models=None, root='~/.insightface'):
         self.available = False
         self.min_confidence = min_confidence
         self.min_face_size = min_face_size
@@ -26,16 +228,127 @@ class FaceAnalyzer:
         self.thumbnail_quality = thumbnail_quality
         self.blink_ear_threshold = blink_ear_threshold
         self.min_faces_for_group = min_faces_for_group
-        print("InsightFace not available: the MI355X engine has no SCRFD/ArcFace graphs yet")
+        self.face_app = None
+        try:
+            if models is None:
+                models = _load_buffalo_l(root)
+            if engine is None:
+                idx = int(str(device).split(':')[1]) if ':' in str(device) else 0
+                engine = Engine(idx)
+            self.face_app = FaceEngine(engine, models, det_size=(640, 640))
+            self.available = True
+        except Exception as e:   # same contract as the reference: report and stay unavailable (face.py:39-40)
+            print(f"InsightFace not available: {e}")
+
+    def _crop_face_thumbnail(self, img_cv, bbox, padding=0.3):
+        try:
+            from PIL import Image
+            x1, y1, x2, y2 = [int(v) for v in bbox]
+            h, w = img_cv.shape[:2]
+            face_w, face_h = x2 - x1, y2 - y1
+            pad_x, pad_y = int(face_w * padding), int(face_h * padding)
+            x1, y1 = max(0, x1 - pad_x), max(0, y1 - pad_y)
+            x2, y2 = min(w, x2 + pad_x), min(h, y2 + pad_y)
+            face_crop = img_cv[y1:y2, x1:x2]
+            if face_crop.size == 0:
+                return None
+            crop_h, crop_w = face_crop.shape[:2]
+            scale = self.thumbnail_size / max(crop_h, crop_w)
+            new_w, new_h = int(crop_w * scale), int(crop_h * scale)
+            im = Image.fromarray(np.ascontiguousarray(face_crop[:, :, ::-1])).resize((new_w, new_h), Image.BOX)
+            buf = io.BytesIO()
+            im.save(buf, format='JPEG', quality=int(self.thumbnail_quality))
+            return buf.getvalue()
+        except Exception:
+            return None
+
+    @staticmethod
+    def _zeros(max_conf=0):
+        return {'face_count': 0, 'face_quality': 0, 'eye_sharpness': 0, 'is_blink': 0, 'face_area': 0, 'bbox': None,
+                'face_sharpness': 0, 'raw_eye_sharpness': 0, 'is_group_portrait': 0, 'max_face_confidence': max_conf,
+                'face_details': []}
 
     def analyze_faces(self, img_cv):
-        # reference face.py:90-97 (the only branch reachable while available is False)
+        if not self.available or img_cv is None:
+            return self._zeros()
+        return self._post(self.face_app.get(img_cv), img_cv)
+
+    def analyze_faces_batch(self, images):
+        """Same-sized BGR images -> list of analyze_faces dicts, with every network run once per batch."""
+        if not self.available or images is None or len(images) == 0:
+            return [self._zeros() for _ in (images if images is not None else [])]
+        arr = np.stack([np.asarray(im) for im in images])
+        return [self._post(faces, arr[i]) for i, faces in enumerate(self.face_app.get_batch(arr))]
+
+    def _post(self, all_faces, img_cv):
+        faces = []
+        max_confidence = 0
+        for face in all_faces:
+            confidence = float(face.det_score)
+            max_confidence = max(max_confidence, confidence)
+            if confidence < self.min_confidence:
+                continue
+            bbox = face.bbox.astype(int)
+            if bbox[2] - bbox[0] < self.min_face_size or bbox[3] - bbox[1] < self.min_face_size:
+                continue
+            faces.append(face)
+        if not faces:
+            return self._zeros(max_confidence)
+        h, w = img_cv.shape[:2]
+        all_qualities, all_eye_scores, all_raw_eye_scores, all_face_sharpness = [], [], [], []
+        any_blink = False
+        total_face_area = 0
+        min_x, min_y, max_x, max_y = w, h, 0, 0
+        for face in faces:
+            bbox = face.bbox.astype(int)
+            min_x, min_y = min(min_x, bbox[0]), min(min_y, bbox[1])
+            max_x, max_y = max(max_x, bbox[2]), max(max_y, bbox[3])
+            all_qualities.append(float(face.det_score * 10))
+            eye_score = 0
+            if face.landmark_2d_106 is not None:
+                l_eye, r_eye = face.landmark_2d_106[38], face.landmark_2d_106[92]
+                offset = int(np.linalg.norm(l_eye - r_eye) * 0.15)
+                eye_vars = []
+                for ex, ey in [l_eye, r_eye]:
+                    ex1, ex2 = int(ex - offset), int(ex + offset)
+                    ey1, ey2 = int(ey - offset), int(ey + offset)
+                    eye_roi = img_cv[max(0, ey1):min(h, ey2), max(0, ex1):min(w, ex2)]
+                    if eye_roi.size > 0:
+                        gray_eye = bgr2gray(eye_roi)
+                        eye_vars.append(laplacian_var(gray_eye) / (np.mean(gray_eye) + 1))
+                eye_score = max(eye_vars) if eye_vars else 0
+            all_eye_scores.append(min(10.0, eye_score / 2.0))
+            all_raw_eye_scores.append(eye_score)
+            all_face_sharpness.append(self._get_crop_sharpness(img_cv, bbox))
+            if self.is_blinking(face):
+                any_blink = True
+            total_face_area += (bbox[2] - bbox[0]) * (bbox[3] - bbox[1])
+        min_quality = min(all_qualities)
+        avg_quality = sum(all_qualities) / len(all_qualities)
+        face_details = []
+        for idx, face in enumerate(faces):
+            bbox = face.bbox.astype(int)
+            face_details.append({
+                'index': idx,
+                'bbox': bbox.tolist(),
+                'confidence': float(face.det_score),
+                'embedding': face.embedding.astype(np.float32).tobytes() if face.embedding is not None else None,
+                'landmark_2d_106': face.landmark_2d_106.astype(np.float32).tobytes() if face.landmark_2d_106 is not None else None,
+                'thumbnail': self._crop_face_thumbnail(img_cv, bbox),
+            })
         return {
-            'face_count': 0, 'face_quality': 0, 'eye_sharpness': 0,
-            'is_blink': 0, 'face_area': 0, 'bbox': None,
-            'face_sharpness': 0, 'raw_eye_sharpness': 0,
-            'is_group_portrait': 0, 'max_face_confidence': 0,
-            'face_details': []
+            'face_obj': faces[0],
+            'face_count': len(faces),
+            'face_quality': round(0.7 * min_quality + 0.3 * avg_quality, 2),
+            'eye_sharpness': round(sum(all_eye_scores) / len(all_eye_scores), 2),
+            'raw_eye_sharpness': sum(all_raw_eye_scores) / len(all_raw_eye_scores),
+            'face_sharpness': sum(all_face_sharpness) / len(all_face_sharpness),
+            'is_blink': 1 if any_blink else 0,
+            'face_area': total_face_area,
+            'bbox': np.array([min_x, min_y, max_x, max_y]),
+            'is_group_portrait': 1 if len(faces) >= self.min_faces_for_group else 0,
+            'max_face_confidence': max_confidence,
+            'face_details': face_details,
         }
 
     @staticmethod
@@ -52,6 +365,15 @@ class FaceAnalyzer:
                 FaceAnalyzer.calculate_ear(landmarks, FaceAnalyzer.RIGHT_EYE_INDICES)) / 2.0
 
     def is_blinking(self, face):
-        if not hasattr(face, 'landmark_2d_106'):
+        lm = face.get('landmark_2d_106') if isinstance(face, dict) else getattr(face, 'landmark_2d_106', None)
+        if lm is None:
             return False
-        return self.compute_avg_ear(face.landmark_2d_106) < self.blink_ear_threshold
+        return self.compute_avg_ear(lm) < self.blink_ear_threshold
+
+    def _get_crop_sharpness(self, img, bbox):
+        h, w = img.shape[:2]
+        y1, y2, x1, x2 = max(0, bbox[1]), min(h, bbox[3]), max(0, bbox[0]), min(w, bbox[2])
+        crop = img[y1:y2, x1:x2]
+        if crop.size == 0:
+            return 0
+        return laplacian_var(bgr2gray(crop))

@@ -163,6 +163,53 @@ int fe_tag_similarities(fe_ctx* ctx, const float* emb, int n, const float* text,
 int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* records,
                       int* models_run);
 
+/* ---- ONNX-subset graph runtime --------------------------------------------------------------------------------
+ * Replaces the onnxruntime InferenceSessions that insightface.app.FaceAnalysis(name='buffalo_l') opens for the reference
+ * (analyzers/face.py:30-38: det_10g.onnx, 2d106det.onnx, w600k_r50.onnx; invoked through face_app.get at :99). The
+ * engine parses the .onnx bytes itself (no protobuf/onnx dependency) and executes the nodes on its own HIP kernels.
+ * Supported operators: Conv (dense and depthwise), Gemm, MatMul (constant B), BatchNormalization, Relu, PRelu, LeakyRelu,
+ * Sigmoid, Add/Sub/Mul/Div, MaxPool, AveragePool, GlobalAveragePool, Resize/Upsample (nearest asymmetric-floor, linear
+ * half-pixel), Concat (channels), Flatten, Reshape, Transpose, Squeeze, Unsqueeze, Softmax, Identity, Dropout, Constant and
+ * the constant shape arithmetic exporters emit (Shape, Gather, Cast, Slice, Concat, Floor, Ceil). Anything else fails with
+ * an error (fe_last_error) naming the operator. One float image input [N,C,H,W]. */
+#define FE_GRAPH_SLOTS 8
+/* Parses an .onnx buffer on the host only (no context, no GPU): counts and the declared input dims, or an error text.
+ * Lets callers validate a model file before a device is involved. Returns FE_OK or FE_ERR_RUNTIME. */
+int fe_onnx_probe(const void* onnx_bytes, size_t len, int* n_nodes, int* n_initializers, int* n_outputs, int64_t in_dims[4],
+                  char* err, int err_cap);
+enum fe_graph_slot { FE_GRAPH_FACE_DET = 0, FE_GRAPH_FACE_LMK = 1, FE_GRAPH_FACE_REC = 2 };
+int fe_graph_load(fe_ctx* ctx, int slot, const void* onnx_bytes, size_t len);
+int fe_graph_unload(fe_ctx* ctx, int slot);
+int fe_graph_loaded(fe_ctx* ctx, int slot);
+/* in_dims: the declared input shape (-1 = dynamic). flags: bit0 / bit1 = a node named Sub* / Mul* (or _minus* / _mul*)
+ * is among the first 8 nodes, the probe insightface uses to choose input mean/std [DEP-KNOWLEDGE]. */
+int fe_graph_info(fe_ctx* ctx, int slot, int* n_nodes, int* n_outputs, int64_t in_dims[4], int* flags);
+/* x: fp32 NCHW (host, or device when on_device). Outputs stay inside the engine until the next run on this slot. */
+int fe_graph_run(fe_ctx* ctx, int slot, const float* x, int n, int c, int h, int w, int on_device);
+int fe_graph_output_info(fe_ctx* ctx, int slot, int i, char* name, int name_cap, int64_t dims[6], int* rank);
+int fe_graph_output_copy(fe_ctx* ctx, int slot, int i, float* dst, size_t cap_floats);
+
+/* ---- face path: what insightface's FaceAnalysis.get does around its three sessions (analyzers/face.py:99) -------------
+ * [DEP-KNOWLEDGE: insightface model_zoo scrfd.py / landmark.py / arcface_onnx.py, utils/face_align.py; OpenCV resize/warpAffine]
+ *
+ * fe_face_detect = SCRFD.detect for a batch of equally sized BGR uint8 images: aspect-preserving cv2.resize (INTER_LINEAR)
+ * into the top-left of a zero det_h x det_w canvas, blobFromImage((x-127.5)/128, swapRB), the graph in FE_GRAPH_FACE_DET,
+ * then per stride: score >= thresh, distance2bbox / distance2kps from anchor centres, / det_scale. Candidates come back
+ * unordered as 16 floats each: score, x1,y1,x2,y2, five (x,y) keypoints, stride level. counts[i] is the number found for
+ * image i (only the first max_cand are stored). Sorting and NMS (tiny, data dependent) stay with the caller.
+ * det_scale_out (nullable) receives new_height / h. */
+int fe_face_detect(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, int det_h, int det_w, float thresh,
+                   int max_cand, float* cand, int* counts, float* det_scale_out);
+/* Warps m square crops with cv2.warpAffine(img[img_index[f]], M[f] (2x3 forward matrix, row-major doubles), (size,size),
+ * borderValue=0), applies blobFromImages((x-mean)*scale, swapRB) and runs graph `slot` on all crops in one batch; out
+ * [m][out_dim] receives its first output. This is face_align.norm_crop + ArcFaceONNX.get_feat (size 112) and
+ * face_align.transform + Landmark.get's forward (size 192). crops_out (nullable) receives the uint8 crops [m][size][size][3];
+ * out may be null when only the crops are wanted. */
+int fe_face_crops_run(fe_ctx* ctx, int slot, const uint8_t* bgr, int n, int h, int w, int on_device, int m, const int* img_index,
+                      const double* M, int size, float mean, float scale, int swap_rb, float* out, int out_dim, uint8_t* crops_out);
+/* cv2.resize(img, (ow, oh)) with INTER_LINEAR on uint8 HWC 3-channel images, the fixed-point path OpenCV takes. */
+int fe_cv_resize_linear_u8(fe_ctx* ctx, const uint8_t* src, int n, int h, int w, int oh, int ow, uint8_t* dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,100 @@
+"""ONNX-subset graph runtime (facet_amd/csrc/onnx_graph.hip) against the torch-CPU ONNX oracle (oracle/onnx_ref.py).
+
+The graphs are seeded stand-ins of the buffalo_l architectures (facet_amd/synthetic_onnx.py); parity is UNPINNED against
+onnxruntime (absent offline) - what is compared is ONNX operator semantics, engine vs oracle, on identical .onnx bytes.
+Tolerance: 1e-3 of the output's max magnitude (fp32 both sides, different summation orders over K up to 25088).
+"""
+import numpy as np
+import pytest
+
+from facet_amd import onnx_writer as W
+from facet_amd import synthetic_onnx as S
+from oracle import onnx_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(engine, data, x, slot=3, tol=1e-3):
+    engine.graph_load(slot, data)
+    got = engine.graph_run(slot, x)
+    want = onnx_ref.run(data, x)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        scale = max(float(np.abs(w).max()), 1e-6)
+        assert float(np.abs(g - w).max()) <= tol * scale, (g.shape, float(np.abs(g - w).max()), scale)
+    engine.graph_unload(slot)
+    return got
+
+
+@pytest.mark.parametrize("explicit_bn", [False, True])
+def test_arcface_small(engine, explicit_bn):
+    data, info = S.arcface_iresnet(layers=(1, 2, 1, 1), seed=3, explicit_bn=explicit_bn)
+    x = np.random.default_rng(1).uniform(-1, 1, (3, 3, 112, 112)).astype(np.float32)
+    _check(engine, data, x)
+
+
+def test_arcface_r50_full(engine):
+    data, info = S.arcface_iresnet(seed=5)
+    assert abs(info["macs"] / 1e9 - 6.3) < 0.2      # ArcFace-R50 @112 ~ 6.3 GMAC
+    x = np.random.default_rng(2).uniform(-1, 1, (2, 3, 112, 112)).astype(np.float32)
+    (emb,) = _check(engine, data, x)
+    assert emb.shape == (2, 512)
+
+
+def test_scrfd_like(engine):
+    data, info = S.scrfd_like(seed=7, size=160)
+    x = np.random.default_rng(3).uniform(-1, 1, (1, 3, 160, 160)).astype(np.float32)
+    outs = _check(engine, data, x)
+    assert [o.shape for o in outs] == [(800, 1), (200, 1), (50, 1), (800, 4), (200, 4), (50, 4), (800, 10), (200, 10), (50, 10)]
+    assert all(0.0 <= float(o.min()) and float(o.max()) <= 1.0 for o in outs[:3])
+
+
+def test_landmark_like(engine):
+    data, info = S.landmark_like(seed=9)
+    x = np.random.default_rng(4).uniform(0, 255, (2, 3, 192, 192)).astype(np.float32)
+    (pts,) = _check(engine, data, x)
+    assert pts.shape == (2, 212)
+    e = engine
+    e.graph_load(3, data)
+    inf = e.graph_info(3)
+    assert inf["has_sub"] and inf["has_mul"] and inf["input_dims"][1:] == [3, 192, 192]
+    e.graph_unload(3)
+
+
+def test_misc_ops(engine):
+    """Operators outside the three big graphs: Concat, GlobalAveragePool, LeakyRelu, linear Resize, MatMul, Softmax, and the
+    Shape/Gather/Concat/Reshape arithmetic torch exporters emit for dynamic views."""
+    g = W.GraphBuilder(21)
+    a = g.conv("x", 3, 24, 3, 2)
+    b = g.op("LeakyRelu", [g.conv("x", 3, 10, 3, 2)], alpha=0.1)
+    c = g.op("Concat", [a, b], axis=1)                         # 34 channels -> padded layout with a gap
+    c = g.relu(g.bn(c, 34))
+    up = g.op("Resize", [c, g.const(np.zeros(0, np.float32)), g.const(np.asarray([1, 1, 2, 2], np.float32))], mode="linear",
+              coordinate_transformation_mode="pytorch_half_pixel")
+    d = g.conv(up, 34, 16, 1, 1, p=0)
+    pooled = g.op("GlobalAveragePool", [d])
+    shp = g.op("Shape", [pooled])
+    n0 = g.op("Gather", [shp, g.const(np.asarray(0, np.int64))], axis=0)
+    n0 = g.op("Unsqueeze", [n0], axes=[0])
+    tgt = g.op("Concat", [n0, g.const(np.asarray([-1], np.int64))], axis=0)
+    flat = g.op("Reshape", [pooled, tgt])
+    mm = g.op("MatMul", [flat, g.const(np.random.default_rng(5).standard_normal((16, 7)).astype(np.float32))])
+    sm = g.op("Softmax", [mm], axis=1)
+    data = g.build([("x", ["N", 3, 40, 56])], [(sm, ["N", 7]), (d, ["N", 16, 40, 56])])
+    x = np.random.default_rng(6).uniform(-1, 1, (2, 3, 40, 56)).astype(np.float32)
+    outs = _check(engine, data, x)
+    assert np.allclose(outs[0].sum(1), 1.0, atol=1e-5)
+
+
+def test_unsupported_operator_is_reported(engine):
+    from facet_amd._lib import EngineError
+    g = W.GraphBuilder(1)
+    y = g.op("Erf", [g.conv("x", 3, 8, 3, 1)])
+    data = g.build([("x", [1, 3, 16, 16])], [(y, [1, 8, 16, 16])])
+    engine.graph_load(3, data)
+    with pytest.raises(EngineError, match="Erf"):
+        engine.graph_run(3, np.zeros((1, 3, 16, 16), np.float32))
+    engine.graph_unload(3)
+    with pytest.raises(EngineError):
+        engine.graph_run(3, np.zeros((1, 3, 16, 16), np.float32))

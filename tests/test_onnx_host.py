@@ -1,0 +1,49 @@
+"""CPU-side checks of the ONNX path: the writer, the C++ wire reader (fe_onnx_probe needs no GPU) and the oracle's own
+reader must agree on the same bytes; malformed files are rejected with a message, not a crash."""
+import numpy as np
+import pytest
+
+from facet_amd import onnx_writer as W
+from facet_amd import synthetic_onnx as S
+from facet_amd._lib import EngineError, onnx_probe
+from oracle import onnx_ref
+
+
+def test_probe_matches_oracle_reader():
+    for fn, kw in ((S.arcface_iresnet, dict(layers=(1, 1, 1, 1))), (S.scrfd_like, dict(size=64)), (S.landmark_like, {})):
+        data, info = fn(**kw)
+        p = onnx_probe(data)
+        m = onnx_ref.parse(data)
+        assert p["nodes"] == len(m["nodes"]) and p["initializers"] == len(m["init"]) and p["outputs"] == len(m["outputs"])
+        assert p["input_dims"][1:] == list(info["input"])
+
+
+def test_writer_roundtrip_values_and_attrs():
+    g = W.GraphBuilder(0)
+    w = np.arange(24, dtype=np.float32).reshape(2, 3, 2, 2) - 7.5
+    n = g.op("Conv", ["x", g.const(w), g.const(np.asarray([-3, 2**40], np.int64))], kernel_shape=[2, 2], strides=[1, 1],
+             pads=[0, 0, 0, 0], alpha=0.25, mode="nearest", neg=-5)
+    data = g.build([("x", ["N", 3, 8, 8])], [(n, ["N", 2, 7, 7])])
+    m = onnx_ref.parse(data)
+    assert m["opset"] == 11 and m["inputs"] == ["x"]
+    (node,) = m["nodes"]
+    assert node["op"] == "Conv" and node["attr"]["kernel_shape"] == [2, 2] and node["attr"]["neg"] == -5
+    assert abs(node["attr"]["alpha"] - 0.25) < 1e-7 and node["attr"]["mode"] == "nearest"
+    assert np.array_equal(m["init"][node["in"][1]], w)
+    assert m["init"][node["in"][2]].tolist() == [-3, 2**40]
+    assert onnx_probe(data)["input_dims"] == [-1, 3, 8, 8]
+
+
+def test_malformed_files_are_rejected():
+    data, _ = S.landmark_like()
+    for bad in (b"", b"\x00" * 16, data[: len(data) // 2], b"not an onnx file at all"):
+        with pytest.raises(EngineError):
+            onnx_probe(bad if bad else b"\x00")
+
+
+def test_oracle_arcface_embedding_is_deterministic():
+    data, _ = S.arcface_iresnet(layers=(1, 1, 1, 1), seed=4)
+    x = np.random.default_rng(0).uniform(-1, 1, (1, 3, 112, 112)).astype(np.float32)
+    a = onnx_ref.run(data, x)[0]
+    b = onnx_ref.run(S.arcface_iresnet(layers=(1, 1, 1, 1), seed=4)[0], x)[0]
+    assert a.shape == (1, 512) and np.array_equal(a, b) and np.isfinite(a).all()
