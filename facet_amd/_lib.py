@@ -17,6 +17,7 @@ FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_SAMP, FE_MODEL_U2NETP, FE_MODEL_AESTHETI
 FE_MODEL_SCRFD, FE_MODEL_ARCFACE = 5, 6
 FE_RECORD_FLOATS = 789
 FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC = 0, 1, 2
+FE_FACE_FLOATS = 739
 FILTERS = {"lanczos": 1, "bilinear": 2, "bicubic": 3}
 ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3}
 
@@ -95,6 +96,8 @@ SIGNATURES = {
                                  _f32p, C.POINTER(C.c_int), _f32p]),
     "fe_face_crops_run": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                     C.POINTER(C.c_double), C.c_int, C.c_float, C.c_float, C.c_int, _f32p, C.c_int, C.c_void_p]),
+    "fe_face_analyze": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                  C.c_int, _f32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fe_cv_resize_linear_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
@@ -478,6 +481,17 @@ class Engine:
                                             out.ctypes.data_as(_f32p) if out_dim else None, int(out_dim),
                                             crops.ctypes.data_as(C.c_void_p) if want_crops else None))
         return out, crops
+
+    def face_analyze(self, images, det_size=(640, 640), det_thresh=0.5, nms_thresh=0.4, max_faces=8):
+        """-> (faces float32 [n,max_faces,739], counts int32 [n], models_run bitmask); layout: include/facet_engine.h."""
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        faces = np.empty((n, max_faces, FE_FACE_FLOATS), np.float32)
+        counts = np.zeros((n,), np.int32)
+        mask = C.c_int(0)
+        self._ck(self.lib.fe_face_analyze(self.h, p, n, h, w, dev, int(det_size[0]), int(det_size[1]), float(det_thresh),
+                                          float(nms_thresh), int(max_faces), faces.ctypes.data_as(_f32p),
+                                          counts.ctypes.data_as(C.POINTER(C.c_int)), C.byref(mask)))
+        return faces, counts, mask.value
 
     def cv_resize_linear(self, imgs, oh, ow):
         a = np.ascontiguousarray(imgs, dtype=np.uint8)

@@ -2,6 +2,7 @@
 #include "../../include/facet_engine.h"
 #include "engine.h"
 #include "onnx_graph.h"
+#include <algorithm>
 #include <cmath>
 #include <tuple>
 
@@ -1026,14 +1027,12 @@ int fe_face_detect(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_
   FE_API_END(ctx)
 }
 
-int fe_face_crops_run(fe_ctx* ctx, int slot, const uint8_t* bgr, int n, int h, int w, int on_device, int m, const int* img_index,
-                      const double* M, int size, float mean, float scale, int swap_rb, float* out, int out_dim, uint8_t* crops_out) {
-  FE_API_BEGIN(ctx)
+// Warps `m` crops out of device-resident images and (optionally) runs graph `gs` on them. d_out: device [m][out_dim] or null;
+// crops_out: host [m][size][size][3] or null. Does not reset the arena; allocates above the caller's mark.
+static void run_face_crops(fe_ctx* ctx, GraphSlot* gs, const uint8_t* d_img, int n, int h, int w, int m, const int* img_index,
+                           const double* M, int size, float mean, float scale, int swap_rb, float* d_out, int out_dim, uint8_t* crops_out) {
   Ctx& C = ctx->c;
-  FE_CHECK(bgr && n > 0 && h > 0 && w > 0 && m >= 0 && size > 0 && (m == 0 || (img_index && M)), "bad arguments");
-  FE_CHECK(out || crops_out, "nothing to compute: both outputs are null");
-  GraphSlot* gs = out ? &graph_slot(ctx, slot) : nullptr;
-  if (m == 0) return FE_OK;
+  if (m <= 0) return;
   if (!ctx->warp_wtab) {
     std::vector<short> wt;
     cv_warp_weight_table(wt);
@@ -1054,21 +1053,13 @@ int fe_face_crops_run(fe_ctx* ctx, int slot, const uint8_t* bgr, int n, int h, i
     o[2] = -o[0] * a[2] - o[1] * a[5];
     o[5] = -o[3] * a[2] - o[4] * a[5];
   }
-  C.arena.reset();
-  const uint8_t* d_img = bgr;
-  if (!on_device) {
-    uint8_t* d = (uint8_t*)C.arena.alloc((size_t)n * h * w * 3);
-    FE_HIP(hipMemcpyAsync(d, bgr, (size_t)n * h * w * 3, hipMemcpyHostToDevice, C.stream));
-    d_img = d;
-  }
   double* d_inv = (double*)C.arena.alloc(inv.size() * sizeof(double));
   int* d_idx = (int*)C.arena.alloc((size_t)m * sizeof(int));
   FE_HIP(hipMemcpyAsync(d_inv, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice, C.stream));
   FE_HIP(hipMemcpyAsync(d_idx, img_index, (size_t)m * sizeof(int), hipMemcpyHostToDevice, C.stream));
   FE_HIP(hipStreamSynchronize(C.stream));   // inv is a local; the copies above must finish before it goes away
-  float* d_out = out ? ctx->out_buf((size_t)m * out_dim) : nullptr;
   const size_t base = C.arena.mark();
-  const int mb = std::max(1, ctx->microbatch * 2);
+  const int mb = std::max(1, ctx->microbatch * 8);   // crops are small (112^2 / 192^2): large batches fill the chip
   for (int f0 = 0; f0 < m; f0 += mb) {
     const int fb = std::min(mb, m - f0);
     C.arena.rewind(base);
@@ -1076,7 +1067,7 @@ int fe_face_crops_run(fe_ctx* ctx, int slot, const uint8_t* bgr, int n, int h, i
     launch_warp_affine(d_img, h, w, d_idx + f0, d_inv + (size_t)f0 * 6, fb, size, ctx->warp_wtab, crops, C.stream);
     if (crops_out)
       FE_HIP(hipMemcpyAsync(crops_out + (size_t)f0 * size * size * 3, crops, (size_t)fb * size * size * 3, hipMemcpyDeviceToHost, C.stream));
-    if (out) {
+    if (d_out) {
       Tensor x = C.arena.tensor(fb, size, size, 4);
       launch_u8_blob(crops, x.p, (size_t)fb * size * size, mean, scale, swap_rb, C.stream);
       std::vector<GraphOutput> outs;
@@ -1085,8 +1076,242 @@ int fe_face_crops_run(fe_ctx* ctx, int slot, const uint8_t* bgr, int n, int h, i
       FE_HIP(hipMemcpyAsync(d_out + (size_t)f0 * out_dim, outs[0].dev, outs[0].numel * sizeof(float), hipMemcpyDeviceToDevice, C.stream));
     }
   }
+}
+
+int fe_face_crops_run(fe_ctx* ctx, int slot, const uint8_t* bgr, int n, int h, int w, int on_device, int m, const int* img_index,
+                      const double* M, int size, float mean, float scale, int swap_rb, float* out, int out_dim, uint8_t* crops_out) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(bgr && n > 0 && h > 0 && w > 0 && m >= 0 && size > 0 && (m == 0 || (img_index && M)), "bad arguments");
+  FE_CHECK(out || crops_out, "nothing to compute: both outputs are null");
+  GraphSlot* gs = out ? &graph_slot(ctx, slot) : nullptr;
+  if (m == 0) return FE_OK;
+  C.arena.reset();
+  const uint8_t* d_img = bgr;
+  if (!on_device) {
+    uint8_t* d = (uint8_t*)C.arena.alloc((size_t)n * h * w * 3);
+    FE_HIP(hipMemcpyAsync(d, bgr, (size_t)n * h * w * 3, hipMemcpyHostToDevice, C.stream));
+    d_img = d;
+  }
+  float* d_out = out ? ctx->out_buf((size_t)m * out_dim) : nullptr;
+  run_face_crops(ctx, gs, d_img, n, h, w, m, img_index, M, size, mean, scale, swap_rb, d_out, out_dim, crops_out);
   if (out) FE_HIP(hipMemcpyAsync(out, d_out, (size_t)m * out_dim * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+// ---- FaceAnalysis.get for a whole batch, host glue in C++ ---------------------------------------------------------------
+extern "C++" {
+namespace {
+struct Cand { float v[16]; };
+// insightface SCRFD.nms on rows sorted by score (fp32 arithmetic like numpy's): returns kept indices in score order
+std::vector<int> face_nms(const std::vector<Cand>& c, float thresh) {
+  const int n = (int)c.size();
+  std::vector<float> area(n);
+  for (int i = 0; i < n; ++i) area[i] = (c[i].v[3] - c[i].v[1] + 1.f) * (c[i].v[4] - c[i].v[2] + 1.f);
+  std::vector<char> dead(n, 0);
+  std::vector<int> keep;
+  for (int i = 0; i < n; ++i) {
+    if (dead[i]) continue;
+    keep.push_back(i);
+    for (int j = i + 1; j < n; ++j) {
+      if (dead[j]) continue;
+      const float xx1 = std::max(c[i].v[1], c[j].v[1]), yy1 = std::max(c[i].v[2], c[j].v[2]);
+      const float xx2 = std::min(c[i].v[3], c[j].v[3]), yy2 = std::min(c[i].v[4], c[j].v[4]);
+      const float ww = std::max(0.0f, xx2 - xx1 + 1.f), hh = std::max(0.0f, yy2 - yy1 + 1.f);
+      const float inter = ww * hh;
+      const float ovr = inter / (area[i] + area[j] - inter);
+      if (!(ovr <= thresh)) dead[j] = 1;
+    }
+  }
+  return keep;
+}
+// least-squares similarity src(5 pts, fp32) -> dst, closed form of Umeyama in 2-D (double); false when degenerate
+bool similarity5(const float* src, const double* dst, double* M) {
+  double sm[2] = {0, 0}, dm[2] = {0, 0};
+  for (int k = 0; k < 5; ++k) { sm[0] += src[2 * k]; sm[1] += src[2 * k + 1]; dm[0] += dst[2 * k]; dm[1] += dst[2 * k + 1]; }
+  for (int a = 0; a < 2; ++a) { sm[a] /= 5.0; dm[a] /= 5.0; }
+  double A[2][2] = {{0, 0}, {0, 0}}, var = 0;
+  for (int k = 0; k < 5; ++k) {
+    const double sx = src[2 * k] - sm[0], sy = src[2 * k + 1] - sm[1], dx = dst[2 * k] - dm[0], dy = dst[2 * k + 1] - dm[1];
+    A[0][0] += dx * sx; A[0][1] += dx * sy; A[1][0] += dy * sx; A[1][1] += dy * sy;
+    var += sx * sx + sy * sy;
+  }
+  for (auto& r : A) for (auto& v : r) v /= 5.0;
+  var /= 5.0;
+  const double p = A[0][0] + A[1][1], q = A[1][0] - A[0][1], r = std::hypot(p, q);
+  if (r == 0.0 || var == 0.0) return false;
+  const double sc = r / var, c = p / r * sc, s = q / r * sc;
+  M[0] = c; M[1] = -s; M[2] = dm[0] - (c * sm[0] - s * sm[1]);
+  M[3] = s; M[4] = c;  M[5] = dm[1] - (s * sm[0] + c * sm[1]);
+  return true;
+}
+const float kArcfaceDst[10] = {38.2946f, 51.6963f, 73.5318f, 51.5014f, 56.0252f, 71.7366f, 41.5493f, 92.3655f, 70.7299f, 92.2041f};
+}  // namespace
+}  // extern "C++"
+
+int fe_face_analyze(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, int det_h, int det_w, float det_thresh,
+                    float nms_thresh, int max_faces, float* faces, int* counts, int* models_run) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  GraphSlot& det = graph_slot(ctx, FE_GRAPH_FACE_DET);
+  GraphSlot* lmk = ctx->c.graphs[FE_GRAPH_FACE_LMK].get();
+  GraphSlot* rec = ctx->c.graphs[FE_GRAPH_FACE_REC].get();
+  FE_CHECK(bgr && faces && counts && n > 0 && h > 0 && w > 0 && max_faces > 0 && det_h >= 32 && det_w >= 32 && det_h % 32 == 0 &&
+               det_w % 32 == 0, "bad arguments");
+  if (models_run) *models_run = 1 | (lmk ? 2 : 0) | (rec ? 4 : 0);
+  const float im_ratio = (float)h / (float)w, model_ratio = (float)det_h / (float)det_w;
+  int new_h, new_w;
+  if (im_ratio > model_ratio) { new_h = det_h; new_w = (int)((float)new_h / im_ratio); }
+  else { new_w = det_w; new_h = (int)((float)new_w * im_ratio); }
+  FE_CHECK(new_h > 0 && new_w > 0, "image aspect ratio leaves an empty detector input");
+  const float det_scale = (float)new_h / (float)h;
+  const bool area2 = (h == 2 * new_h && w == 2 * new_w), copy_only = (h == new_h && w == new_w);
+  auto tx = cv_resize_tab(ctx, w, new_w, true), ty = cv_resize_tab(ctx, h, new_h, false);
+  const size_t no = det.g.model().outputs.size();
+  int fmc, K = 0, A;
+  if (no == 6) { fmc = 3; A = 2; }
+  else if (no == 9) { fmc = 3; A = 2; K = 5; }
+  else if (no == 10) { fmc = 5; A = 1; }
+  else if (no == 15) { fmc = 5; A = 1; K = 5; }
+  else FE_CHECK(false, "detector graph has %zu outputs; SCRFD layouts have 6, 9, 10 or 15", no);
+  static const int kS3[3] = {8, 16, 32}, kS5[5] = {8, 16, 32, 64, 128};
+  const int* strides = fmc == 3 ? kS3 : kS5;
+  auto graph_norm = [](GraphSlot* g, float dflt_std, float* mean, float* scale, int* size, int dflt_size) {
+    const bool self = g->g.head_has_sub() && g->g.head_has_mul();
+    *mean = self ? 0.f : 127.5f;
+    *scale = 1.0f / (self ? 1.0f : dflt_std);
+    const auto& d = g->g.model().inputs[0].dims;
+    *size = (d.size() == 4 && d[2] > 0) ? (int)d[2] : dflt_size;
+  };
+  float lm_mean = 0, lm_scale = 1, rc_mean = 0, rc_scale = 1;
+  int lm_size = 192, rc_size = 112;
+  if (lmk) graph_norm(lmk, 128.0f, &lm_mean, &lm_scale, &lm_size, 192);
+  if (rec) graph_norm(rec, 127.5f, &rc_mean, &rc_scale, &rc_size, 112);
+  const auto& lo = lmk ? lmk->g.model().outputs[0].dims : std::vector<int64_t>();
+  const int lm_dim = (lmk && !lo.empty() && lo.back() > 0) ? (int)lo.back() : 212;
+  FE_CHECK(!lmk || lm_dim == 212, "landmark graph yields %d values per face; the record layout holds 106 x 2", lm_dim);
+  const auto& ro = rec ? rec->g.model().outputs[0].dims : std::vector<int64_t>();
+  const int rc_dim = (rec && !ro.empty() && ro.back() > 0) ? (int)ro.back() : 512;
+  FE_CHECK(!rec || rc_dim == 512, "recognition graph yields %d values per face; the record layout holds 512", rc_dim);
+
+  const int max_cand = 4096;
+  const size_t per = (size_t)h * w * 3;
+  const int mbn = ctx->microbatch;
+  memset(faces, 0, (size_t)n * max_faces * FE_FACE_FLOATS * sizeof(float));
+  std::vector<float> h_cand((size_t)mbn * max_cand * 16), h_lmk, h_emb;
+  std::vector<int> h_counts(mbn);
+  // device image access for the crop stage: resident input is used in place; host input is staged per micro-batch
+  ImageStager st(ctx, bgr, n, per, mbn, on_device);
+  for (int k = 0; k < st.chunks(); ++k) {
+    const int i0 = k * mbn, nb = st.count(k);
+    C.arena.reset();
+    const uint8_t* d_in = st.get(k);
+    float* d_cand = (float*)C.arena.alloc((size_t)nb * max_cand * 16 * sizeof(float));
+    int* d_counts = (int*)C.arena.alloc((size_t)nb * sizeof(int));
+    FE_HIP(hipMemsetAsync(d_counts, 0, (size_t)nb * sizeof(int), C.stream));
+    const size_t keep_mark = C.arena.mark();
+    uint8_t* canvas = (uint8_t*)C.arena.alloc((size_t)nb * det_h * det_w * 3);
+    FE_HIP(hipMemsetAsync(canvas, 0, (size_t)nb * det_h * det_w * 3, C.stream));
+    if (copy_only) {
+      for (int b = 0; b < nb; ++b)
+        FE_HIP(hipMemcpy2DAsync(canvas + (size_t)b * det_h * det_w * 3, (size_t)det_w * 3, d_in + (size_t)b * per, (size_t)w * 3, (size_t)w * 3, h,
+                                hipMemcpyDeviceToDevice, C.stream));
+    } else {
+      launch_cv_resize_linear(d_in, nb, h, w, canvas, det_h, det_w, new_h, new_w, tx.ofs, tx.coef, ty.ofs, ty.coef, area2 ? 1 : 0, C.stream);
+    }
+    Tensor x = C.arena.tensor(nb, det_h, det_w, 4);
+    launch_u8_blob(canvas, x.p, (size_t)nb * det_h * det_w, 127.5f, 1.0f / 128.0f, 1, C.stream);
+    std::vector<GraphOutput> outs;
+    det.g.run(C, x, 3, outs);
+    for (int l = 0; l < fmc; ++l) {
+      const int s = strides[l], fh = det_h / s, fw = det_w / s;
+      const size_t rows = (size_t)nb * fh * fw * A;
+      FE_CHECK(outs[l].numel == rows && outs[l + fmc].numel == rows * 4 && (!K || outs[l + 2 * fmc].numel == rows * 2 * K),
+               "detector output %d has %zu values, expected %zu rows for stride %d", l, outs[l].numel, rows, s);
+      launch_scrfd_decode(outs[l].dev, outs[l + fmc].dev, K ? outs[l + 2 * fmc].dev : nullptr, nb, fh, fw, A, K, s, det_thresh, det_scale, l,
+                          d_cand, d_counts, max_cand, C.stream);
+    }
+    FE_HIP(hipMemcpyAsync(h_counts.data(), d_counts, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, C.stream));
+    FE_HIP(hipStreamSynchronize(C.stream));
+    int maxc = 0;
+    for (int b = 0; b < nb; ++b) { h_counts[b] = std::min(h_counts[b], max_cand); maxc = std::max(maxc, h_counts[b]); }
+    if (maxc > 0) {
+      FE_HIP(hipMemcpy2DAsync(h_cand.data(), (size_t)maxc * 16 * sizeof(float), d_cand, (size_t)max_cand * 16 * sizeof(float),
+                              (size_t)maxc * 16 * sizeof(float), nb, hipMemcpyDeviceToHost, C.stream));
+      FE_HIP(hipStreamSynchronize(C.stream));
+    }
+    // host: sort by score (ties: level, x1, y1 - deterministic), NMS, keep the best max_faces
+    std::vector<int> f_img;
+    std::vector<Cand> f_c;
+    for (int b = 0; b < nb; ++b) {
+      std::vector<Cand> c(h_counts[b]);
+      for (int q = 0; q < h_counts[b]; ++q) memcpy(c[q].v, &h_cand[((size_t)b * maxc + q) * 16], 16 * sizeof(float));
+      std::sort(c.begin(), c.end(), [](const Cand& a, const Cand& b2) {
+        if (a.v[0] != b2.v[0]) return a.v[0] > b2.v[0];
+        if (a.v[15] != b2.v[15]) return a.v[15] < b2.v[15];
+        if (a.v[1] != b2.v[1]) return a.v[1] < b2.v[1];
+        return a.v[2] < b2.v[2];
+      });
+      std::vector<int> keep = face_nms(c, nms_thresh);
+      counts[i0 + b] = (int)keep.size();
+      for (int q = 0; q < (int)keep.size() && q < max_faces; ++q) { f_img.push_back(b); f_c.push_back(c[keep[q]]); }
+    }
+    const int m = (int)f_c.size();
+    C.arena.rewind(keep_mark);   // detector activations are no longer needed; candidates were copied out
+    float *d_lmk = nullptr, *d_emb = nullptr;
+    std::vector<double> Ml((size_t)m * 6), Mr((size_t)m * 6);
+    if (m > 0 && lmk) {
+      for (int f = 0; f < m; ++f) {   // Landmark.get: face_align.transform(img, center, size, size / (max(w,h) * 1.5), 0)
+        const double x1 = f_c[f].v[1], y1 = f_c[f].v[2], x2 = f_c[f].v[3], y2 = f_c[f].v[4];
+        const double bw = x2 - x1, bh = y2 - y1, cx = (x2 + x1) / 2, cy = (y2 + y1) / 2;
+        const double sc = lm_size / (std::max(bw, bh) * 1.5);
+        double* M = &Ml[(size_t)f * 6];
+        M[0] = sc; M[1] = 0; M[2] = -cx * sc + lm_size / 2.0;
+        M[3] = 0; M[4] = sc; M[5] = -cy * sc + lm_size / 2.0;
+      }
+      d_lmk = (float*)C.arena.alloc((size_t)m * 212 * sizeof(float));
+      run_face_crops(ctx, lmk, d_in, nb, h, w, m, f_img.data(), Ml.data(), lm_size, lm_mean, lm_scale, 1, d_lmk, 212, nullptr);
+      h_lmk.resize((size_t)m * 212);
+      FE_HIP(hipMemcpyAsync(h_lmk.data(), d_lmk, h_lmk.size() * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+    }
+    std::vector<char> rec_ok(m, 0);
+    if (m > 0 && rec && K == 5) {
+      double dst[10];
+      for (int q = 0; q < 10; ++q) dst[q] = (double)kArcfaceDst[q] * ((double)rc_size / 112.0);
+      for (int f = 0; f < m; ++f) {
+        rec_ok[f] = similarity5(&f_c[f].v[5], dst, &Mr[(size_t)f * 6]) ? 1 : 0;
+        if (!rec_ok[f]) { double* M = &Mr[(size_t)f * 6]; M[0] = M[4] = 1; M[1] = M[2] = M[3] = M[5] = 0; }
+      }
+      const size_t mk = C.arena.mark();
+      d_emb = (float*)C.arena.alloc((size_t)m * 512 * sizeof(float));
+      run_face_crops(ctx, rec, d_in, nb, h, w, m, f_img.data(), Mr.data(), rc_size, rc_mean, rc_scale, 1, d_emb, 512, nullptr);
+      h_emb.resize((size_t)m * 512);
+      FE_HIP(hipMemcpyAsync(h_emb.data(), d_emb, h_emb.size() * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+      (void)mk;
+    }
+    FE_HIP(hipStreamSynchronize(C.stream));
+    st.done(k);
+    std::vector<int> slot_of(nb, 0);
+    for (int f = 0; f < m; ++f) {
+      const int b = f_img[f];
+      float* o = faces + ((size_t)(i0 + b) * max_faces + slot_of[b]++) * FE_FACE_FLOATS;
+      o[0] = f_c[f].v[1]; o[1] = f_c[f].v[2]; o[2] = f_c[f].v[3]; o[3] = f_c[f].v[4]; o[4] = f_c[f].v[0];
+      memcpy(o + 5, &f_c[f].v[5], 10 * sizeof(float));
+      if (d_lmk) {   // pred in [-1,1] -> crop pixels -> image through the inverse crop matrix (trans_points2d)
+        const double* M = &Ml[(size_t)f * 6];
+        const double D = 1.0 / (M[0] * M[4]);   // rotation 0: diagonal matrix
+        const double i00 = M[4] * D, i11 = M[0] * D, i02 = -i00 * M[2], i12 = -i11 * M[5];
+        for (int q = 0; q < 106; ++q) {
+          const float px = (h_lmk[(size_t)f * 212 + 2 * q] + 1.f) * (float)(lm_size / 2);
+          const float py = (h_lmk[(size_t)f * 212 + 2 * q + 1] + 1.f) * (float)(lm_size / 2);
+          o[15 + 2 * q] = (float)(i00 * (double)px + 0.0 * (double)py + i02);
+          o[16 + 2 * q] = (float)(0.0 * (double)px + i11 * (double)py + i12);
+        }
+      }
+      if (d_emb && rec_ok[f]) memcpy(o + 15 + 212, &h_emb[(size_t)f * 512], 512 * sizeof(float));
+    }
+  }
   FE_API_END(ctx)
 }
 

@@ -107,11 +107,35 @@ def laplacian_var(gray):
     return float(lap.var())
 
 
+class _GraphsHandle:
+    """What ModelManager pokes at when it parks a model in RAM: .cpu() frees the device graphs, .to(dev) loads them again."""
+
+    def __init__(self, fe):
+        self._fe = fe
+
+    def cpu(self):
+        self._fe.unload()
+        return self
+
+    def to(self, device):
+        if str(device) == 'cpu':
+            self._fe.unload()
+        else:
+            self._fe.load()
+        return self
+
+    def eval(self):
+        return self
+
+
 class FaceEngine:
     """insightface.app.FaceAnalysis for batches: detection -> landmark_2d_106 -> recognition on the engine."""
 
-    def __init__(self, engine, models, det_size=(640, 640), det_thresh=0.5, nms_thresh=0.4, max_candidates=1024):
+    def __init__(self, engine, models, det_size=(640, 640), det_thresh=0.5, nms_thresh=0.4, max_candidates=1024, max_faces=64):
         self.engine = engine
+        self.max_faces = max_faces
+        self._models = dict(models)
+        self.model = _GraphsHandle(self)
         self.det_size, self.det_thresh, self.nms_thresh, self.max_candidates = det_size, det_thresh, nms_thresh, max_candidates
         if "det" not in models:
             raise EngineError("face models: a detection model is required")     # FaceAnalysis asserts 'detection' in models
@@ -126,6 +150,11 @@ class FaceEngine:
                 info = engine.graph_info(slot)
                 self.norm[key] = (0.0, 1.0) if (info["has_sub"] and info["has_mul"]) else (127.5, default_std)
                 self.norm[key + "_size"] = int(info["input_dims"][2]) if info["input_dims"][2] > 0 else (192 if key == "lmk" else 112)
+
+    def load(self):
+        for key, slot in (("det", FE_GRAPH_FACE_DET), ("lmk", FE_GRAPH_FACE_LMK), ("rec", FE_GRAPH_FACE_REC)):
+            if key in self._models and not self.engine.graph_loaded(slot):
+                self.engine.graph_load(slot, self._models[key])
 
     def unload(self):
         for slot in (FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC):
@@ -148,7 +177,28 @@ class FaceEngine:
         return out
 
     def get_batch(self, images):
-        """FaceAnalysis.get for every image of a same-sized BGR batch; returns list (per image) of list[Face]."""
+        """FaceAnalysis.get for every image of a same-sized BGR batch; returns list (per image) of list[Face].
+        One engine call (fe_face_analyze): detection, NMS, landmarks and embeddings for the whole batch. Images with more than
+        `max_faces` detections keep the best-scoring max_faces (insightface keeps all; raise max_faces if that matters)."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        rec, counts, mask = self.engine.face_analyze(images, self.det_size, self.det_thresh, self.nms_thresh, self.max_faces)
+        out = []
+        for i in range(images.shape[0]):
+            faces = []
+            for f in range(min(int(counts[i]), self.max_faces)):
+                r = rec[i, f]
+                face = Face(bbox=r[0:4].copy(), det_score=r[4], kps=r[5:15].reshape(5, 2).copy())
+                if mask & 2:
+                    face['landmark_2d_106'] = r[15:227].reshape(106, 2).copy()
+                if mask & 4:
+                    face['embedding'] = r[227:739].copy()
+                faces.append(face)
+            out.append(faces)
+        return out
+
+    def get_batch_host(self, images):
+        """The same pipeline with the glue (sort, NMS, crop matrices, back-projection) in numpy on top of fe_face_detect /
+        fe_face_crops_run. Kept as the readable statement of what fe_face_analyze does natively; tests cross-check the two."""
         images = np.ascontiguousarray(images, dtype=np.uint8)
         n, h, w, _ = images.shape
         e = self.engine

@@ -12,7 +12,7 @@ from ._lib import Engine, EngineError
 
 # runtime estimates the reference uses for pass packing (model_manager.py:652-667)
 MODEL_VRAM_GB = {'clip': 4, 'clip_aesthetic': 4, 'samp_net': 2, 'insightface': 2, 'topiq': 2}
-HOT_PATH_MODELS = ('topiq', 'clip', 'samp_net')
+HOT_PATH_MODELS = ('topiq', 'clip', 'samp_net', 'insightface')
 
 
 class ModelManager:
@@ -108,6 +108,16 @@ class ModelManager:
         if name == 'clip':
             from .clip import load_clip
             return load_clip(self.engine, cfg.get('clip', {}).get('model_path'))
+        if name == 'insightface':
+            # reference _load_insightface (model_manager.py:462-480) returns insightface's FaceAnalysis app (.get(img));
+            # FaceEngine is that object on the engine. Model files: <root>/models/buffalo_l/*.onnx, never downloaded.
+            from .face import FaceEngine, _load_buffalo_l
+            fcfg = cfg.get('insightface', {})
+            try:
+                models = fcfg.get('models') or _load_buffalo_l(fcfg.get('root', '~/.insightface'))
+            except FileNotFoundError as e:
+                raise EngineError(str(e))
+            return FaceEngine(self.engine, models, det_size=(640, 640))
         raise KeyError(f"model '{name}' is not served by the engine (hot-path models: {HOT_PATH_MODELS})")
 
     @staticmethod

@@ -207,6 +207,17 @@ int fe_face_detect(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_
  * out may be null when only the crops are wanted. */
 int fe_face_crops_run(fe_ctx* ctx, int slot, const uint8_t* bgr, int n, int h, int w, int on_device, int m, const int* img_index,
                       const double* M, int size, float mean, float scale, int swap_rb, float* out, int out_dim, uint8_t* crops_out);
+/* FaceAnalysis.get(img) for a whole batch in ONE call (reference: face_app.get at analyzers/face.py:99, once per image):
+ * fe_face_detect's pipeline, then on the host side of the engine score-sort + NMS(nms_thresh) per image, then for the best
+ * max_faces faces of every image: Landmark.get (192-crop, graph FE_GRAPH_FACE_LMK, back-projection) and ArcFaceONNX.get
+ * (5-point similarity crop 112, graph FE_GRAPH_FACE_REC), both batched over all faces of a micro-batch. Input normalisation
+ * per graph follows insightface's Sub/Mul probe. faces [n][max_faces][FE_FACE_FLOATS]: bbox x1,y1,x2,y2, det_score,
+ * kps[5][2], landmark_2d_106[106][2], embedding[512] (zeros for absent models / unused slots); counts[i] = faces that
+ * survived NMS for image i (may exceed max_faces). models_run (nullable): 1 det | 2 landmarks | 4 recognition.
+ * The fixed-size slots are what ranks all-gather in multi-GPU runs. */
+#define FE_FACE_FLOATS 739
+int fe_face_analyze(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, int det_h, int det_w, float det_thresh,
+                    float nms_thresh, int max_faces, float* faces, int* counts, int* models_run);
 /* cv2.resize(img, (ow, oh)) with INTER_LINEAR on uint8 HWC 3-channel images, the fixed-point path OpenCV takes. */
 int fe_cv_resize_linear_u8(fe_ctx* ctx, const uint8_t* src, int n, int h, int w, int oh, int ow, uint8_t* dst);
 

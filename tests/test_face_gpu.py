@@ -67,7 +67,7 @@ def test_detect_matches_oracle(engine, models):
 
 
 def test_face_analysis_end_to_end(engine, models):
-    fe = FaceEngine(engine, models, det_size=(320, 320), max_candidates=4096)
+    fe = FaceEngine(engine, models, det_size=(320, 320), max_candidates=4096, max_faces=256)
     assert fe.norm["lmk"] == (0.0, 1.0) and fe.norm["rec"] == (127.5, 127.5) and fe.norm["lmk_size"] == 192 and fe.norm["rec_size"] == 112
     imgs = np.random.default_rng(9).integers(0, 256, (2, 288, 352, 3), dtype=np.uint8)
     got = fe.get_batch(imgs)
@@ -85,6 +85,18 @@ def test_face_analysis_end_to_end(engine, models):
             em = face_ref.arcface_get(models["rec"], imgs[i], g.kps, 127.5, 127.5)
             assert np.abs(g.landmark_2d_106 - lm).max() < 1e-4 * max(1.0, np.abs(lm).max())
             assert np.abs(g.embedding - em).max() < 1e-4 * np.abs(em).max()
+    # native glue (fe_face_analyze: C++ sort/NMS/crop matrices/back-projection) == numpy glue on the same engine kernels
+    host = fe.get_batch_host(imgs)
+    for i in range(2):
+        assert len(host[i]) == len(got[i])
+        for g, hface in zip(got[i], host[i]):
+            assert np.array_equal(g.bbox, hface.bbox) and g.det_score == hface.det_score and np.array_equal(g.kps, hface.kps)
+            assert np.abs(g.landmark_2d_106 - hface.landmark_2d_106).max() <= 1e-4 * max(1.0, np.abs(hface.landmark_2d_106).max())
+            assert np.abs(g.embedding - hface.embedding).max() <= 1e-5 * np.abs(hface.embedding).max()
+    fe.max_faces = 3      # capacity smaller than the detections: best-scoring faces are kept, counts still report all
+    capped = fe.get_batch(imgs)
+    assert all(len(c) == min(3, len(g)) for c, g in zip(capped, got))
+    assert all(np.array_equal(c[0].bbox, g[0].bbox) for c, g in zip(capped, got))
     fe.unload()
 
 
@@ -93,6 +105,7 @@ def test_face_analyzer_dict_matches_reference_logic(engine, models):
     assert fa.available
     fa.face_app.det_size = (320, 320)
     fa.face_app.max_candidates = 4096
+    fa.face_app.max_faces = 256
     imgs = np.random.default_rng(10).integers(0, 256, (2, 320, 320, 3), dtype=np.uint8)
     res = fa.analyze_faces_batch(list(imgs))
     single = fa.analyze_faces(imgs[1])
