@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "images/sec whole-node (TOPIQ+SAMP+CLIP+InsightFace ensemble), 1024² batch"
+FACES_PER_IMAGE = 2
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -40,8 +41,29 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
     net = ld(CFANet(), "topiq")
     imgs = synthetic_images(2, sample, hw, hw)
     cores = torch.get_num_threads()
-    extra = None
-    if workload == "ensemble":
+    extras = []
+    if workload in ("faces", "full"):
+        from PIL import Image
+        from oracle.sampnet import U2NETP, SAMPNet
+        from oracle import face_ref
+        from facet_amd import synthetic_onnx as SO
+        u2, sn = ld(U2NETP(), "u2netp"), ld(SAMPNet(), "samp_net")
+        im_m, im_s = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+        fm = {"det": (SO.scrfd_like(seed=12, size=640)[0], 127.5, 128.0), "lmk": (SO.landmark_like(seed=13)[0], 0.0, 1.0),
+              "rec": (SO.arcface_iresnet(seed=14)[0], 127.5, 127.5)}
+
+        def extra_faces(batch):
+            for a in batch:      # per image, like analyzers/face.py:99 and multi_pass.py:540-547
+                if workload == "faces":
+                    x = torch.from_numpy(np.asarray(Image.fromarray(a).resize((224, 224), Image.BILINEAR), np.float32) / 255).permute(2, 0, 1)[None]
+                    x = (x - im_m) / im_s
+                    sn(x, u2(x))
+                det, kpss = face_ref.scrfd_detect(fm["det"][0], a, (640, 640))
+                for f in range(min(FACES_PER_IMAGE, det.shape[0])):
+                    face_ref.landmark_get(fm["lmk"][0], a, det[f, :4], 192, 0.0, 1.0)
+                    face_ref.arcface_get(fm["rec"][0], a, kpss[f], 127.5, 127.5)
+        extras.append(extra_faces)
+    if workload in ("ensemble", "full"):
         from PIL import Image
         from oracle.clip_vit import CLIPImage, aesthetic_head, CLIP_MEAN, CLIP_STD
         from oracle.sampnet import U2NETP, SAMPNet
@@ -49,7 +71,7 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
         im_m, im_s = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
         cl_m, cl_s = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(CLIP_STD).view(1, 3, 1, 1)
 
-        def extra(batch):
+        def extra_ens(batch):
             pils = [Image.fromarray(a) for a in batch]
             c_in = torch.stack([torch.from_numpy(np.asarray(p.resize((224, 224), Image.BICUBIC), np.float32) / 255).permute(2, 0, 1)
                                 for p in pils])
@@ -59,6 +81,7 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
                 x = torch.from_numpy(np.asarray(p.resize((224, 224), Image.BILINEAR), np.float32) / 255).permute(2, 0, 1)[None]
                 x = (x - im_m) / im_s
                 sn(x, u2(x))
+        extras.append(extra_ens)
     with torch.no_grad():
         x = torch.from_numpy(imgs[:1].astype(np.float32) / 255.0).permute(0, 3, 1, 2)
         net(x)  # warm
@@ -66,10 +89,13 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
         for i in range(sample):
             x = torch.from_numpy(imgs[i:i + 1].astype(np.float32) / 255.0).permute(0, 3, 1, 2)
             net(x)
-        if extra is not None:
-            extra(imgs)
+        for ex in extras:
+            ex(imgs)
         dt = time.perf_counter() - t0
-    what = "oracle/topiq.py CFANet" if workload == "topiq" else "oracle TOPIQ + CLIP ViT-L/14 + aesthetic MLP + U2NETP + SAMPNet"
+    what = {"topiq": "oracle/topiq.py CFANet", "ensemble": "oracle TOPIQ + CLIP ViT-L/14 + aesthetic MLP + U2NETP + SAMPNet",
+            "faces": f"oracle TOPIQ + U2NETP + SAMPNet + face_ref SCRFD@640/landmarks/ArcFace ({FACES_PER_IMAGE} faces/image)",
+            "full": f"oracle TOPIQ + CLIP ViT-L/14 + aesthetic MLP + U2NETP + SAMPNet + face_ref SCRFD@640/landmarks/ArcFace "
+                    f"({FACES_PER_IMAGE} faces/image)"}[workload]
     return {"value": round(sample / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{sample} x {hw}x{hw} synthetic RGB through {what} (torch {torch.__version__} CPU fp32, {cores} "
                       "threads; TOPIQ/SAMP one image per forward, CLIP one batch)"}
@@ -83,8 +109,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--microbatch", type=int, default=32)
-    ap.add_argument("--workload", choices=["topiq", "ensemble"], default="topiq",
-                    help="topiq = BASELINE.json configs[1]; ensemble = TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP")
+    ap.add_argument("--workload", choices=["topiq", "ensemble", "faces", "full"], default="topiq",
+                    help="topiq = BASELINE.json configs[1]; ensemble = TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP; "
+                         "faces = configs[2]: TOPIQ + SAMP-Net + SCRFD/landmarks/ArcFace; full = the metric's whole ensemble "
+                         "(TOPIQ + SAMP + CLIP + InsightFace-style faces)")
     ap.add_argument("--cpu-sample", type=int, default=4, help="images for the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -116,11 +144,21 @@ def main():
     B, HW = args.batch, args.size
     eng = Engine(dev_index, arena_bytes=(4 + 2 * args.microbatch * max(1, (HW * HW) // (1024 * 1024))) << 30)
     eng.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", seed=3))
-    if args.workload == "ensemble":
+    if args.workload in ("ensemble", "full"):
         eng.load_weights(FE_MODEL_CLIP, synthetic_state_dict("clip", seed=3))
         eng.load_weights(FE_MODEL_AESTHETIC, synthetic_state_dict("aesthetic", seed=3))
+    if args.workload in ("ensemble", "faces", "full"):
         eng.load_weights(FE_MODEL_U2NETP, synthetic_state_dict("u2netp", seed=3))
         eng.load_weights(FE_MODEL_SAMP, synthetic_state_dict("samp_net", seed=3))
+    if args.workload in ("faces", "full"):
+        # BASELINE.json configs[2]: TOPIQ + SAMP-Net + InsightFace. Seeded stand-in graphs of the buffalo_l architectures
+        # (no model files offline); uniform-noise images carry no real faces, so the best FACES_PER_IMAGE detections of the
+        # synthetic detector go through landmarks + ArcFace (fixed faces-per-image mode).
+        from facet_amd import synthetic_onnx as SO
+        from facet_amd._lib import FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC
+        eng.graph_load(FE_GRAPH_FACE_DET, SO.scrfd_like(seed=12, size=640)[0])
+        eng.graph_load(FE_GRAPH_FACE_LMK, SO.landmark_like(seed=13)[0])
+        eng.graph_load(FE_GRAPH_FACE_REC, SO.arcface_iresnet(seed=14)[0])
     eng.set_microbatch(args.microbatch)
 
     # this rank's shard of the global batch (weak scaling: B images per GPU), generated once, resident in HBM
@@ -144,6 +182,13 @@ def main():
         if args.workload == "ensemble":
             rec, mask = eng.ensemble_score(images)      # [B, 789] per-image records
             assert mask == 7
+            return gather_scores(rec, world, dev_index)
+        if args.workload in ("faces", "full"):
+            rec, mask = eng.ensemble_score(images)      # faces: TOPIQ + SAMP fields only (CLIP not loaded)
+            assert mask == (5 if args.workload == "faces" else 7)
+            faces, counts, fmask = eng.face_analyze(images, (640, 640), 0.5, 0.4, FACES_PER_IMAGE)   # noise serves as BGR
+            assert fmask == 7
+            rec = np.concatenate([rec, counts[:, None].astype(np.float32), faces.reshape(B, -1)], axis=1)
             return gather_scores(rec, world, dev_index)
         scores = eng.topiq_score(images)
         return gather_scores(scores, world, dev_index)
@@ -186,6 +231,12 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"TOPIQ-NR (ResNet-50 pyramid + CFANet head) fp32, batch {B}/GPU, {HW}x{HW} RGB "
                                     "(BASELINE.json configs[1])") if args.workload == "topiq" else
+                                   (f"TOPIQ + SAMP-Net/U2-Net-P + InsightFace-style SCRFD detect @640 + 2d106 landmarks + ArcFace-R50 "
+                                    f"({FACES_PER_IMAGE} best faces/image, seeded stand-in ONNX graphs) fp32, batch {B}/GPU, {HW}x{HW} "
+                                    "(BASELINE.json configs[2])") if args.workload == "faces" else
+                                   (f"whole ensemble of the metric: TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP + InsightFace-style "
+                                    f"SCRFD@640 / 2d106 landmarks / ArcFace-R50 ({FACES_PER_IMAGE} best faces/image, stand-in ONNX graphs) fp32, "
+                                    f"batch {B}/GPU, {HW}x{HW}") if args.workload == "full" else
                                    (f"ensemble TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP fp32 (no InsightFace), "
                                     f"batch {B}/GPU, {HW}x{HW} RGB"),
                        "global_batch": B * world, "image_size": HW, "microbatch": args.microbatch,

@@ -179,7 +179,7 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
     launch_tap_gather(z.p, Tp, x.n, x.h, x.w, w.KH, w.KW, o.ph, o.pw, o.dh, o.dw, w.Cout, w.scale, w.shift, o.act, y.p,
                       y.ld, y.h, y.w, c.stream);
     c.arena.rewind(mark);
-    c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * p.Cout;
+    c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout);
     return;
   }
   if (c.profile) {
@@ -195,11 +195,11 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
     char nm[128];
     snprintf(nm, sizeof nm, "conv%dx%d s%d d%d M=%d K=%d N=%d", w.KH, w.KW, o.sh, o.dh, p.M, p.K, p.Cout);
     double bytes = 4.0 * ((double)x.pixels() * x.c + (double)y.pixels() * y.c * (o.res ? 2 : 1) + (double)w.Cout * w.K);
-    c.timings.push_back({nm, 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * p.Cout, bytes, ms});
+    c.timings.push_back({nm, 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout), bytes, ms});
   } else {
     launch_conv(p, c.stream);
   }
-  c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * p.Cout;
+  c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout);
 }
 
 Tensor conv_new(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o) {
@@ -282,7 +282,7 @@ void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, floa
   if (M <= 32 && !res && act != ACT_PRELU && c.force_variant == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w.w) & 15) == 0) {
     // per-image vectors: stream the weight matrix once instead of idling 255 CUs behind one 128-row tile
     launch_gemm_skinny(x, ldx, w.w, w.Kp, w.scale, w.shift, y, ldy, M, w.Cout, w.K, act, c.stream);
-    c.flops_accum += 2.0 * M * (double)w.Cin * w.Cout;
+    c.flops_accum += 2.0 * M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : w.Cout);
     return;
   }
   Tensor xt = mat_view(x, M, w.CinPad, ldx), yt = mat_view(y, M, w.Cout, ldy);

@@ -130,6 +130,7 @@ struct ConvW {
   float* shift = nullptr;  // [Cout] or null
   float* slope = nullptr;  // [Cout] PReLU slopes or null
   int Cout = 0, Cin = 0, CinPad = 0, KH = 1, KW = 1, K = 0, Kp = 0;
+  int CoutAlg = 0;         // logical output channels when Cout carries zero padding (FLOP accounting only; 0 => Cout)
   // Cout <= 2 spatial kernels also carry a tap-decomposed form: rows (tap, co) of a 1x1 conv [KH*KW*Cout][KpT]
   float* wtap = nullptr;
   int KpT = 0;

@@ -549,7 +549,8 @@ void Graph::exec_group(Ctx& c, int idx) {
             }
       }
       nc.cw = pack_conv(dw_, hw, sc.empty() ? nullptr : &sc, any_shift ? &sh : nullptr);
-      nc.cw.Cin = is_conv ? Cin_l : nc.cw.Cin;
+      nc.cw.Cin = Cin_l;          // algorithmic (unpadded) sizes for the FLOP counter
+      nc.cw.CoutAlg = Cout;
     }
     if (g.act >= 0 && act_code(m_.nodes[g.act]) == ACT_PRELU) {
       std::vector<float> sl;
