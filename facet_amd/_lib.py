@@ -18,6 +18,7 @@ FE_MODEL_SCRFD, FE_MODEL_ARCFACE = 5, 6
 FE_RECORD_FLOATS = 789
 FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC = 0, 1, 2
 FE_FACE_FLOATS = 739
+FE_STATS_DOUBLES = 264
 FILTERS = {"lanczos": 1, "bilinear": 2, "bicubic": 3}
 ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3}
 
@@ -98,6 +99,7 @@ SIGNATURES = {
                                     C.POINTER(C.c_double), C.c_int, C.c_float, C.c_float, C.c_int, _f32p, C.c_int, C.c_void_p]),
     "fe_face_analyze": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                   C.c_int, _f32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fe_image_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
     "fe_cv_resize_linear_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
@@ -492,6 +494,17 @@ class Engine:
                                           float(nms_thresh), int(max_faces), faces.ctypes.data_as(_f32p),
                                           counts.ctypes.data_as(C.POINTER(C.c_int)), C.byref(mask)))
         return faces, counts, mask.value
+
+    def image_stats(self, images, want_gray=False, want_hsv=False):
+        """BGR uint8 [n,h,w,3] (or device tuple) -> (stats float64 [n,264], gray uint8 [n,h,w] | None, hsv uint8 [n,h,w,3] | None)."""
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        stats = np.empty((n, FE_STATS_DOUBLES), np.float64)
+        gray = np.empty((n, h, w), np.uint8) if want_gray else None
+        hsv = np.empty((n, h, w, 3), np.uint8) if want_hsv else None
+        self._ck(self.lib.fe_image_stats(self.h, p, n, h, w, dev, stats.ctypes.data_as(C.POINTER(C.c_double)),
+                                         gray.ctypes.data_as(C.c_void_p) if want_gray else None,
+                                         hsv.ctypes.data_as(C.c_void_p) if want_hsv else None))
+        return stats, gray, hsv
 
     def cv_resize_linear(self, imgs, oh, ow):
         a = np.ascontiguousarray(imgs, dtype=np.uint8)

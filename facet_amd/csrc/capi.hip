@@ -20,6 +20,7 @@ struct fe_ctx {
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
   // face path: device copies of OpenCV's interpolation tables (built once / per size)
   short* warp_wtab = nullptr;
+  int* hsv_sdiv = nullptr; int* hsv_hdiv = nullptr;   // cv2 HSV division tables
   struct CvResizeTab { int* ofs; short* coef; };
   std::map<std::tuple<int, int, int>, CvResizeTab> cvresize;   // (src, dst, clamp) -> tables
   std::vector<void*> misc_allocs;
@@ -1329,6 +1330,42 @@ int fe_cv_resize_linear_u8(fe_ctx* ctx, const uint8_t* src, int n, int h, int w,
   else launch_cv_resize_linear(d_src, n, h, w, d_dst, oh, ow, oh, ow, tx.ofs, tx.coef, ty.ofs, ty.coef, (h == 2 * oh && w == 2 * ow) ? 1 : 0, C.stream);
   FE_HIP(hipMemcpyAsync(dst, d_dst, (size_t)n * oh * ow * 3, hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+/* Per-image technical statistics of a BGR batch (reference analyzers/image_cache.py:28-33 + analyzers/technical.py) */
+int fe_image_stats(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, double* stats, uint8_t* gray_out, uint8_t* hsv_out) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(bgr && stats && n > 0 && h > 0 && w > 0, "bad arguments");
+  if (!ctx->hsv_sdiv) {
+    std::vector<int> sd, hd;
+    cv_hsv_tables(sd, hd);
+    FE_HIP(hipMalloc((void**)&ctx->hsv_sdiv, 256 * sizeof(int)));
+    ctx->misc_allocs.push_back(ctx->hsv_sdiv);
+    FE_HIP(hipMalloc((void**)&ctx->hsv_hdiv, 256 * sizeof(int)));
+    ctx->misc_allocs.push_back(ctx->hsv_hdiv);
+    FE_HIP(hipMemcpy(ctx->hsv_sdiv, sd.data(), 256 * sizeof(int), hipMemcpyHostToDevice));
+    FE_HIP(hipMemcpy(ctx->hsv_hdiv, hd.data(), 256 * sizeof(int), hipMemcpyHostToDevice));
+  }
+  const size_t per = (size_t)h * w * 3, npx = (size_t)h * w;
+  const int mb = std::max(1, ctx->microbatch);
+  ImageStager st(ctx, bgr, n, per, mb, on_device);
+  for (int k = 0; k < st.chunks(); ++k) {
+    const int i0 = k * mb, nb = st.count(k);
+    C.arena.reset();
+    const uint8_t* d_in = st.get(k);
+    uint8_t* d_gray = (uint8_t*)C.arena.alloc((size_t)nb * npx);
+    uint8_t* d_hsv = hsv_out ? (uint8_t*)C.arena.alloc((size_t)nb * per) : nullptr;
+    void* d_acc = C.arena.alloc(stats_accum_bytes(nb));
+    double* d_out = (double*)C.arena.alloc((size_t)nb * FE_STATS_COUNT * sizeof(double));
+    launch_image_stats(d_in, nb, h, w, d_gray, d_hsv, ctx->hsv_sdiv, ctx->hsv_hdiv, d_acc, d_out, C.stream);
+    st.done(k);
+    FE_HIP(hipMemcpyAsync(stats + (size_t)i0 * FE_STATS_COUNT, d_out, (size_t)nb * FE_STATS_COUNT * sizeof(double), hipMemcpyDeviceToHost, C.stream));
+    if (gray_out) FE_HIP(hipMemcpyAsync(gray_out + (size_t)i0 * npx, d_gray, (size_t)nb * npx, hipMemcpyDeviceToHost, C.stream));
+    if (hsv_out) FE_HIP(hipMemcpyAsync(hsv_out + (size_t)i0 * per, d_hsv, (size_t)nb * per, hipMemcpyDeviceToHost, C.stream));
+    FE_HIP(hipStreamSynchronize(C.stream));   // the arena is recycled by the next micro-batch
+  }
   FE_API_END(ctx)
 }
 

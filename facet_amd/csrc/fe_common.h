@@ -219,4 +219,13 @@ void launch_scrfd_decode(const float* scores, const float* bbox, const float* kp
 void cv_resize_tables(int src, int dst, bool clamp_fx, std::vector<int>& ofs, std::vector<short>& coef);
 void cv_warp_weight_table(std::vector<short>& wtab);
 
+// ---------------------------------------------------------------------------------------
+// Per-image technical statistics (kernels_stats.hip)
+// ---------------------------------------------------------------------------------------
+constexpr int FE_STATS_COUNT = 264;   // doubles per image: [0..255] gray histogram, 256 lap sum, 257 lap sum sq, 258 sum|Immerkaer|, 259 sum S, 260 sum c*log2(c) over the H-S histogram
+size_t stats_accum_bytes(int n);
+void launch_image_stats(const uint8_t* bgr, int n, int h, int w, uint8_t* gray, uint8_t* hsv_out, const int* sdiv, const int* hdiv, void* accum,
+                        double* out, hipStream_t s);
+void cv_hsv_tables(std::vector<int>& sdiv, std::vector<int>& hdiv);
+
 }  // namespace fe

@@ -92,9 +92,9 @@ def nms(dets, thresh=0.4):
 
 
 def bgr2gray(img):
-    """cv2.cvtColor(img, COLOR_BGR2GRAY) for uint8: 14-bit fixed point (R 4899, G 9617, B 1868)."""
+    """cv2.cvtColor(img, COLOR_BGR2GRAY) for uint8: 15-bit fixed point (R 9798, G 19235, B 3735; OpenCV 4.x)."""
     a = img.astype(np.int32)
-    return ((a[..., 0] * 1868 + a[..., 1] * 9617 + a[..., 2] * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+    return ((a[..., 0] * 3735 + a[..., 1] * 19235 + a[..., 2] * 9798 + (1 << 14)) >> 15).astype(np.uint8)
 
 
 def laplacian_var(gray):

@@ -221,6 +221,18 @@ int fe_face_analyze(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on
 /* cv2.resize(img, (ow, oh)) with INTER_LINEAR on uint8 HWC 3-channel images, the fixed-point path OpenCV takes. */
 int fe_cv_resize_linear_u8(fe_ctx* ctx, const uint8_t* src, int n, int h, int w, int oh, int ow, uint8_t* dst);
 
+/* ---- per-image technical statistics ----------------------------------------------------------------
+ * The scans reference analyzers/image_cache.py:28-33 (cv2.cvtColor BGR2GRAY / BGR2HSV, cv2.Laplacian(CV_64F).var()) and
+ * analyzers/technical.py:39-342 (calcHist 256 / 180x256, saturation mean, percentiles, Immerkaer cv2.filter2D) run per image
+ * on the CPU, as two HBM-bound GPU passes over a BGR uint8 batch. stats [n][FE_STATS_DOUBLES] (all exact integers except
+ * [260]): [0..255] gray histogram counts; [256] sum and [257] sum of squares of the 4-neighbour Laplacian (reflect-101 border);
+ * [258] sum |Immerkaer 3x3 response|; [259] sum of HSV saturation; [260] sum c*log2(c) over the 180x256 hue-saturation
+ * histogram (entropy = log2(N) - [260]/N); [261..263] reserved. gray_out [n][h][w] / hsv_out [n][h][w][3] (nullable) return
+ * the converted images themselves. facet_amd/image_stats.py turns the record into the reference's seven metric dicts. */
+#define FE_STATS_DOUBLES 264
+int fe_image_stats(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, double* stats, uint8_t* gray_out,
+                   uint8_t* hsv_out);
+
 #ifdef __cplusplus
 }
 #endif

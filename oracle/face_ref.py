@@ -115,7 +115,7 @@ def warp_affine_u8(img, M, size):
 
 def bgr2gray(img):
     b, g, r = (img[..., k].astype(np.int64) for k in range(3))
-    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+    return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
 
 
 def laplacian_var(gray):
