@@ -1349,7 +1349,8 @@ int fe_image_stats(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_
     FE_HIP(hipMemcpy(ctx->hsv_hdiv, hd.data(), 256 * sizeof(int), hipMemcpyHostToDevice));
   }
   const size_t per = (size_t)h * w * 3, npx = (size_t)h * w;
-  const int mb = std::max(1, ctx->microbatch);
+  // two blocks per image in pass 1: large chunks keep all 256 CUs busy (the footprint is only ~2-5 bytes per pixel)
+  const int mb = std::max(1, std::max(ctx->microbatch, 256));
   ImageStager st(ctx, bgr, n, per, mb, on_device);
   for (int k = 0; k < st.chunks(); ++k) {
     const int i0 = k * mb, nb = st.count(k);

@@ -26,32 +26,36 @@ __device__ __forceinline__ int gray_of(int b, int g, int r) { return (b * 3735 +
 __global__ __launch_bounds__(1024) void stats_pass1_kernel(const uint8_t* __restrict__ bgr, int h, int w, uint8_t* __restrict__ gray,
                                                            uint8_t* __restrict__ hsv_out, const int* __restrict__ sdiv,
                                                            const int* __restrict__ hdiv, StatsAccum* __restrict__ acc) {
-  extern __shared__ unsigned int lds[];          // [90*256] hue-sat counts of this half, then [256] gray histogram
+  extern __shared__ unsigned int lds[];          // [90*256] hue-sat counts of this half, [256] gray histogram, 2 x [256] tables
   const int half = blockIdx.x, img = blockIdx.y;
   unsigned int* hs = lds;
   unsigned int* gh = lds + 90 * 256;
+  int* sdiv_l = reinterpret_cast<int*>(lds + 90 * 256 + 256);   // the two division tables, copied next to the histograms:
+  int* hdiv_l = sdiv_l + 256;                                   // per-pixel lookups are scattered, LDS serves them cheaply
   for (int i = threadIdx.x; i < 90 * 256 + 256; i += blockDim.x) lds[i] = 0;
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv_l[i] = sdiv[i]; hdiv_l[i] = hdiv[i]; }
   __syncthreads();
   const size_t npx = (size_t)h * w;
   const uint8_t* src = bgr + (size_t)img * npx * 3;
   long long sat = 0;
-  for (size_t p = threadIdx.x; p < npx; p += blockDim.x) {
-    const int b = src[p * 3], g = src[p * 3 + 1], r = src[p * 3 + 2];
+  // gray / saturation / plane output are shared between the two blocks of an image by loop-step parity, so both blocks carry
+  // the same number of LDS atomics
+  auto one_pixel = [&](bool do_gray, int b, int g, int r, int* gray_v, int* h_v, int* s_v, int* v_v) {
     int v = b > g ? b : g; v = v > r ? v : r;
     int vmin = b < g ? b : g; vmin = vmin < r ? vmin : r;
     const int diff = v - vmin;
     const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
-    const int s = (diff * sdiv[v] + (1 << 11)) >> 12;
+    const int s = (diff * sdiv_l[v] + (1 << 11)) >> 12;
     int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
-    hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
+    hh = (hh * hdiv_l[diff] + (1 << 11)) >> 12;
     hh += hh < 0 ? 180 : 0;
     hh = hh > 255 ? 255 : hh;
-    if (half == 0) {
+    *h_v = hh; *s_v = s; *v_v = v;
+    if (do_gray) {
       const int y = gray_of(b, g, r);
-      gray[(size_t)img * npx + p] = (uint8_t)y;
+      *gray_v = y;
       atomicAdd(&gh[y], 1u);
       sat += s;
-      if (hsv_out) { uint8_t* o = hsv_out + ((size_t)img * npx + p) * 3; o[0] = (uint8_t)hh; o[1] = (uint8_t)s; o[2] = (uint8_t)v; }
     }
     const int hl = hh - half * 90;
     const bool mine = hl >= 0 && hl < 90;
@@ -64,6 +68,48 @@ __global__ __launch_bounds__(1024) void stats_pass1_kernel(const uint8_t* __rest
     } else if (bin >= 0) {
       atomicAdd(&hs[bin], 1u);
     }
+  };
+  if ((npx & 3) == 0) {
+    // 4 pixels = 12 bytes = 3 dwords per thread and step (image bases stay 4-byte aligned because npx % 4 == 0); the next
+    // step's dwords are requested before this step's pixels are processed
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+    const size_t groups = npx >> 2;
+    size_t q = threadIdx.x;
+    uint32_t d0 = 0, d1 = 0, d2 = 0;
+    if (q < groups) { d0 = s32[q * 3]; d1 = s32[q * 3 + 1]; d2 = s32[q * 3 + 2]; }
+    while (q < groups) {
+      const size_t qn = q + blockDim.x;
+      uint32_t e0 = 0, e1 = 0, e2 = 0;
+      if (qn < groups) { e0 = s32[qn * 3]; e1 = s32[qn * 3 + 1]; e2 = s32[qn * 3 + 2]; }
+      const int px[12] = {(int)(d0 & 255), (int)((d0 >> 8) & 255), (int)((d0 >> 16) & 255), (int)(d0 >> 24),
+                          (int)(d1 & 255), (int)((d1 >> 8) & 255), (int)((d1 >> 16) & 255), (int)(d1 >> 24),
+                          (int)(d2 & 255), (int)((d2 >> 8) & 255), (int)((d2 >> 16) & 255), (int)(d2 >> 24)};
+      int gy[4] = {0, 0, 0, 0}, hv[4], sv[4], vv[4];
+      const bool mine_g = (int)((q / blockDim.x) & 1) == half;   // block-uniform per step
+#pragma unroll
+      for (int k = 0; k < 4; ++k) one_pixel(mine_g, px[3 * k], px[3 * k + 1], px[3 * k + 2], &gy[k], &hv[k], &sv[k], &vv[k]);
+      if (mine_g) {
+        reinterpret_cast<uint32_t*>(gray + (size_t)img * npx)[q] = (uint32_t)gy[0] | ((uint32_t)gy[1] << 8) | ((uint32_t)gy[2] << 16) | ((uint32_t)gy[3] << 24);
+        if (hsv_out) {
+          uint32_t* o = reinterpret_cast<uint32_t*>(hsv_out + (size_t)img * npx * 3) + q * 3;
+          o[0] = (uint32_t)hv[0] | ((uint32_t)sv[0] << 8) | ((uint32_t)vv[0] << 16) | ((uint32_t)hv[1] << 24);
+          o[1] = (uint32_t)sv[1] | ((uint32_t)vv[1] << 8) | ((uint32_t)hv[2] << 16) | ((uint32_t)sv[2] << 24);
+          o[2] = (uint32_t)vv[2] | ((uint32_t)hv[3] << 8) | ((uint32_t)sv[3] << 16) | ((uint32_t)vv[3] << 24);
+        }
+      }
+      d0 = e0; d1 = e1; d2 = e2;
+      q = qn;
+    }
+  } else {
+    for (size_t p = threadIdx.x; p < npx; p += blockDim.x) {
+      int gy = 0, hv, sv, vv;
+      const bool mine_g = (int)((p / blockDim.x) & 1) == half;
+      one_pixel(mine_g, src[p * 3], src[p * 3 + 1], src[p * 3 + 2], &gy, &hv, &sv, &vv);
+      if (mine_g) {
+        gray[(size_t)img * npx + p] = (uint8_t)gy;
+        if (hsv_out) { uint8_t* o = hsv_out + ((size_t)img * npx + p) * 3; o[0] = (uint8_t)hv; o[1] = (uint8_t)sv; o[2] = (uint8_t)vv; }
+      }
+    }
   }
   __syncthreads();
   // entropy term of this half: sum c*log2(c); wave-reduced, one atomic per wave
@@ -74,11 +120,10 @@ __global__ __launch_bounds__(1024) void stats_pass1_kernel(const uint8_t* __rest
   }
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
   if ((threadIdx.x & 63) == 0 && part != 0.0) atomicAdd(&acc[img].hs_clog2c, part);
-  if (half == 0) {
-    for (int o = 32; o > 0; o >>= 1) sat += __shfl_xor(sat, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)&acc[img].sat_sum, (unsigned long long)sat);
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) acc[img].hist[i] = gh[i];
-  }
+  for (int o = 32; o > 0; o >>= 1) sat += __shfl_xor(sat, o);
+  if ((threadIdx.x & 63) == 0 && sat) atomicAdd((unsigned long long*)&acc[img].sat_sum, (unsigned long long)sat);
+  for (int i = threadIdx.x; i < 256; i += blockDim.x)
+    if (gh[i]) atomicAdd(&acc[img].hist[i], gh[i]);
 }
 
 __device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }   // BORDER_REFLECT_101
@@ -136,7 +181,7 @@ void launch_image_stats(const uint8_t* bgr, int n, int h, int w, uint8_t* gray, 
   FE_CHECK(n > 0 && h > 0 && w > 0 && (size_t)h * w < (1ull << 31), "image_stats: bad shape");
   StatsAccum* acc = (StatsAccum*)accum;
   FE_HIP(hipMemsetAsync(acc, 0, stats_accum_bytes(n), s));
-  constexpr size_t lds = (size_t)(90 * 256 + 256) * sizeof(unsigned int);
+  constexpr size_t lds = (size_t)(90 * 256 + 256 + 512) * sizeof(unsigned int);
   static bool attr_set = false;
   if (!attr_set) {
     FE_HIP(hipFuncSetAttribute((const void*)stats_pass1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

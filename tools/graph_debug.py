@@ -2,7 +2,7 @@
 (which also disables epilogue fusion - compare with the fused run to tell kernel bugs from fusion bugs)."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from facet_amd import synthetic_onnx as S, onnx_writer as W
 from facet_amd._lib import Engine
 from oracle import onnx_ref

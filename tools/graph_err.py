@@ -1,7 +1,7 @@
 """Prints engine-vs-oracle relative errors of the synthetic face graphs (sanity for tolerances)."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from facet_amd import synthetic_onnx as S
 from facet_amd._lib import Engine
 from oracle import onnx_ref

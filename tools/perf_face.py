@@ -2,7 +2,7 @@
 and landmark graphs on batches of crops. Synthetic stand-in graphs (facet_amd/synthetic_onnx.py)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from facet_amd import synthetic_onnx as S
 from facet_amd._lib import Engine, FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC
 

@@ -1,7 +1,7 @@
 """Host-buffer vs device-resident throughput of the image entry points (PCIe-inclusive rates for DESIGN.md)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from facet_amd._lib import Engine, FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_SAMP, FE_MODEL_U2NETP, FE_MODEL_AESTHETIC
 from facet_amd import weights as W
 

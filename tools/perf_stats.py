@@ -1,7 +1,7 @@
 """fe_image_stats throughput on a resident 1024x1024 BGR batch, noise and flat content (flat = worst case for histogram atomics)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from facet_amd._lib import Engine
 e = Engine(0, arena_bytes=8 << 30)
 e.set_microbatch(32)
