@@ -100,6 +100,8 @@ SIGNATURES = {
     "fe_face_analyze": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                   C.c_int, _f32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fe_image_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
+    "fe_roi_laplacian": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_double)]),
     "fe_cv_resize_linear_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
@@ -505,6 +507,16 @@ class Engine:
                                          gray.ctypes.data_as(C.c_void_p) if want_gray else None,
                                          hsv.ctypes.data_as(C.c_void_p) if want_hsv else None))
         return stats, gray, hsv
+
+    def roi_laplacian(self, images, img_index, rois):
+        """rois int [m,4] (x1,y1,x2,y2 exclusive, clipped) -> float64 [m,4]: sum lap, sum lap^2, sum gray, pixel count."""
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        idx = np.ascontiguousarray(img_index, dtype=np.int32)
+        r = np.ascontiguousarray(rois, dtype=np.int32).reshape(-1, 4)
+        out = np.zeros((idx.shape[0], 4), np.float64)
+        self._ck(self.lib.fe_roi_laplacian(self.h, p, n, h, w, dev, idx.shape[0], idx.ctypes.data_as(C.POINTER(C.c_int)),
+                                           r.ctypes.data_as(C.POINTER(C.c_int)), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
 
     def cv_resize_linear(self, imgs, oh, ow):
         a = np.ascontiguousarray(imgs, dtype=np.uint8)

@@ -1370,4 +1370,34 @@ int fe_image_stats(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_
   FE_API_END(ctx)
 }
 
+/* Laplacian statistics of m rectangular ROIs of a BGR batch (reference analyzers/face.py:160-176, 272-279) */
+int fe_roi_laplacian(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, int m, const int* img_index, const int* rois,
+                     double* out) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(bgr && n > 0 && h > 0 && w > 0 && m >= 0 && (m == 0 || (img_index && rois && out)), "bad arguments");
+  if (m == 0) return FE_OK;
+  for (int f = 0; f < m; ++f) {
+    FE_CHECK(img_index[f] >= 0 && img_index[f] < n, "roi %d refers to image %d of %d", f, img_index[f], n);
+    const int* r = rois + 4 * f;
+    FE_CHECK(r[0] >= 0 && r[1] >= 0 && r[2] <= w && r[3] <= h, "roi %d = [%d,%d,%d,%d] leaves the %dx%d image", f, r[0], r[1], r[2], r[3], w, h);
+  }
+  C.arena.reset();
+  const uint8_t* d_img = bgr;
+  if (!on_device) {
+    uint8_t* d = (uint8_t*)C.arena.alloc((size_t)n * h * w * 3);
+    FE_HIP(hipMemcpyAsync(d, bgr, (size_t)n * h * w * 3, hipMemcpyHostToDevice, C.stream));
+    d_img = d;
+  }
+  int* d_idx = (int*)C.arena.alloc((size_t)m * sizeof(int));
+  int* d_roi = (int*)C.arena.alloc((size_t)m * 4 * sizeof(int));
+  double* d_out = (double*)C.arena.alloc((size_t)m * 4 * sizeof(double));
+  FE_HIP(hipMemcpyAsync(d_idx, img_index, (size_t)m * sizeof(int), hipMemcpyHostToDevice, C.stream));
+  FE_HIP(hipMemcpyAsync(d_roi, rois, (size_t)m * 4 * sizeof(int), hipMemcpyHostToDevice, C.stream));
+  launch_roi_laplacian(d_img, h, w, d_idx, d_roi, m, d_out, C.stream);
+  FE_HIP(hipMemcpyAsync(out, d_out, (size_t)m * 4 * sizeof(double), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
 }  // extern "C"

@@ -227,5 +227,7 @@ size_t stats_accum_bytes(int n);
 void launch_image_stats(const uint8_t* bgr, int n, int h, int w, uint8_t* gray, uint8_t* hsv_out, const int* sdiv, const int* hdiv, void* accum,
                         double* out, hipStream_t s);
 void cv_hsv_tables(std::vector<int>& sdiv, std::vector<int>& hdiv);
+// rois: device int [m][4] = x1,y1,x2,y2 (already clipped to the image, x2/y2 exclusive); out: device double [m][4]
+void launch_roi_laplacian(const uint8_t* bgr, int h, int w, const int* img_of, const int* rois, int m, double* out, hipStream_t s);
 
 }  // namespace fe

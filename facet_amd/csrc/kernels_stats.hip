@@ -173,6 +173,53 @@ __global__ void stats_pack_kernel(const StatsAccum* __restrict__ acc, int n, dou
   }
 }
 
+// ---- Laplacian statistics of rectangular ROIs (face post-processing) ----------------------------------------
+// Reference analyzers/face.py:160-176 (eye ROIs) and :272-279 (face crop): cv2.cvtColor(roi, BGR2GRAY) then
+// cv2.Laplacian(gray, CV_64F).var() and np.mean(gray) on a numpy slice - the border rule (reflect-101) applies at the ROI
+// edge, not the image edge. One block per ROI; gray is recomputed from BGR on the fly (ROIs are small).
+// out per ROI: [0] sum lap, [1] sum lap^2, [2] sum gray, [3] pixel count (exact integers in doubles).
+__global__ __launch_bounds__(256) void roi_laplacian_kernel(const uint8_t* __restrict__ bgr, int h, int w, const int* __restrict__ img_of,
+                                                            const int* __restrict__ rois, int m, double* __restrict__ out) {
+  const int f = blockIdx.x;
+  if (f >= m) return;
+  const int x1 = rois[4 * f], y1 = rois[4 * f + 1], x2 = rois[4 * f + 2], y2 = rois[4 * f + 3];
+  const int rw = x2 - x1, rh = y2 - y1;
+  __shared__ long long red[3][4];
+  long long lsum = 0, lsq = 0, gsum = 0;
+  if (rw > 0 && rh > 0) {
+    const uint8_t* src = bgr + (size_t)img_of[f] * h * w * 3;
+    auto G = [&](int yy, int xx) {
+      const uint8_t* p = src + ((size_t)(y1 + yy) * w + (x1 + xx)) * 3;
+      return gray_of(p[0], p[1], p[2]);
+    };
+    const int total = rw * rh;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int y = i / rw, x = i - y * rw;
+      const int ym = rh > 1 ? (y - 1 < 0 ? 1 : y - 1) : 0, yp = rh > 1 ? (y + 1 >= rh ? rh - 2 : y + 1) : 0;
+      const int xm = rw > 1 ? (x - 1 < 0 ? 1 : x - 1) : 0, xp = rw > 1 ? (x + 1 >= rw ? rw - 2 : x + 1) : 0;
+      const int c = G(y, x);
+      const int lap = G(ym, x) + G(yp, x) + G(y, xm) + G(y, xp) - 4 * c;
+      lsum += lap; lsq += lap * lap; gsum += c;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { lsum += __shfl_xor(lsum, o); lsq += __shfl_xor(lsq, o); gsum += __shfl_xor(gsum, o); }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = lsum; red[1][wv] = lsq; red[2][wv] = gsum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = out + (size_t)f * 4;
+    o[0] = (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    o[1] = (double)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    o[2] = (double)(red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+    o[3] = (rw > 0 && rh > 0) ? (double)rw * rh : 0.0;
+  }
+}
+void launch_roi_laplacian(const uint8_t* bgr, int h, int w, const int* img_of, const int* rois, int m, double* out, hipStream_t s) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(roi_laplacian_kernel, dim3(m), dim3(256), 0, s, bgr, h, w, img_of, rois, m, out);
+  FE_HIP(hipGetLastError());
+}
+
 size_t stats_accum_bytes(int n) { return (size_t)n * sizeof(StatsAccum); }
 
 // gray: device [n][h][w] scratch (always written); hsv_out: nullable device [n][h][w][3]; out: device [n][ST_COUNT] doubles

@@ -102,7 +102,8 @@ def laplacian_var(gray):
     if gray.size == 0:
         return 0.0
     g = gray.astype(np.float64)
-    p = np.pad(g, 1, mode="reflect") if min(g.shape) > 1 else np.pad(g, 1, mode="edge")
+    p = np.pad(g, ((1, 1), (0, 0)), mode="reflect" if g.shape[0] > 1 else "edge")      # BORDER_REFLECT_101 per axis; a
+    p = np.pad(p, ((0, 0), (1, 1)), mode="reflect" if g.shape[1] > 1 else "edge")      # length-1 axis repeats its only sample
     lap = p[:-2, 1:-1] + p[2:, 1:-1] + p[1:-1, :-2] + p[1:-1, 2:] - 4.0 * g
     return float(lap.var())
 
@@ -180,10 +181,11 @@ class FaceEngine:
         """FaceAnalysis.get for every image of a same-sized BGR batch; returns list (per image) of list[Face].
         One engine call (fe_face_analyze): detection, NMS, landmarks and embeddings for the whole batch. Images with more than
         `max_faces` detections keep the best-scoring max_faces (insightface keeps all; raise max_faces if that matters)."""
-        images = np.ascontiguousarray(images, dtype=np.uint8)
+        if not isinstance(images, tuple):       # (device_ptr, n, h, w) batches are used in place
+            images = np.ascontiguousarray(images, dtype=np.uint8)
         rec, counts, mask = self.engine.face_analyze(images, self.det_size, self.det_thresh, self.nms_thresh, self.max_faces)
         out = []
-        for i in range(images.shape[0]):
+        for i in range(rec.shape[0]):
             faces = []
             for f in range(min(int(counts[i]), self.max_faces)):
                 r = rec[i, f]
@@ -327,10 +329,39 @@ class FaceAnalyzer:
         """Same-sized BGR images -> list of analyze_faces dicts, with every network run once per batch."""
         if not self.available or images is None or len(images) == 0:
             return [self._zeros() for _ in (images if images is not None else [])]
-        arr = np.stack([np.asarray(im) for im in images])
-        return [self._post(faces, arr[i]) for i, faces in enumerate(self.face_app.get_batch(arr))]
+        arr = np.ascontiguousarray(np.stack([np.asarray(im) for im in images]), dtype=np.uint8)
+        e = self.face_app.engine
+        d = e.dev_alloc(arr.nbytes)
+        try:
+            e.h2d(d, arr)
+            dev = (d, arr.shape[0], arr.shape[1], arr.shape[2])
+            per_image = self.face_app.get_batch(dev)
+            # first pass only records which ROIs the reference logic looks at; one engine call scans them all
+            wanted = []
+            for i, faces in enumerate(per_image):
+                self._post(faces, arr[i], lambda x1, y1, x2, y2, i=i: (wanted.append((i, x1, y1, x2, y2)), (0.0, 0.0))[1], thumbnails=False)
+            table = {}
+            if wanted:
+                st = e.roi_laplacian(dev, [r[0] for r in wanted], [r[1:] for r in wanted])
+                for r, (ls, lss, gs, cnt) in zip(wanted, st):
+                    mean = ls / cnt
+                    table[r] = (lss / cnt - mean * mean, gs / cnt)
+        finally:
+            e.dev_free(d)
+        return [self._post(faces, arr[i], lambda x1, y1, x2, y2, i=i: table[(i, x1, y1, x2, y2)]) for i, faces in enumerate(per_image)]
 
-    def _post(self, all_faces, img_cv):
+    @staticmethod
+    def _roi_numpy(img_cv):
+        def fn(x1, y1, x2, y2):
+            g = bgr2gray(img_cv[y1:y2, x1:x2])
+            return laplacian_var(g), float(np.mean(g))
+        return fn
+
+    def _post(self, all_faces, img_cv, roi_stats=None, thumbnails=True):
+        """reference analyze_faces :101-234. roi_stats(x1,y1,x2,y2) -> (Laplacian variance, mean gray) of a non-empty clipped ROI;
+        default: numpy on the host image (single-image path), batch path: fe_roi_laplacian results."""
+        if roi_stats is None:
+            roi_stats = self._roi_numpy(img_cv)
         faces = []
         max_confidence = 0
         for face in all_faces:
@@ -362,14 +393,17 @@ class FaceAnalyzer:
                 for ex, ey in [l_eye, r_eye]:
                     ex1, ex2 = int(ex - offset), int(ex + offset)
                     ey1, ey2 = int(ey - offset), int(ey + offset)
-                    eye_roi = img_cv[max(0, ey1):min(h, ey2), max(0, ex1):min(w, ex2)]
-                    if eye_roi.size > 0:
-                        gray_eye = bgr2gray(eye_roi)
-                        eye_vars.append(laplacian_var(gray_eye) / (np.mean(gray_eye) + 1))
+                    # the reference slices img_cv[max(0,ey1):min(h,ey2), max(0,ex1):min(w,ex2)]: a negative upper bound counts
+                    # from the far edge in numpy; slice.indices reproduces exactly the region numpy would cut
+                    ry1, ry2, _ = slice(max(0, ey1), min(h, ey2)).indices(h)
+                    rx1, rx2, _ = slice(max(0, ex1), min(w, ex2)).indices(w)
+                    if rx2 > rx1 and ry2 > ry1:          # eye_roi.size > 0
+                        var, mean_gray = roi_stats(rx1, ry1, rx2, ry2)
+                        eye_vars.append(var / (mean_gray + 1))
                 eye_score = max(eye_vars) if eye_vars else 0
             all_eye_scores.append(min(10.0, eye_score / 2.0))
             all_raw_eye_scores.append(eye_score)
-            all_face_sharpness.append(self._get_crop_sharpness(img_cv, bbox))
+            all_face_sharpness.append(self._get_crop_sharpness(img_cv, bbox, roi_stats))
             if self.is_blinking(face):
                 any_blink = True
             total_face_area += (bbox[2] - bbox[0]) * (bbox[3] - bbox[1])
@@ -384,7 +418,7 @@ class FaceAnalyzer:
                 'confidence': float(face.det_score),
                 'embedding': face.embedding.astype(np.float32).tobytes() if face.embedding is not None else None,
                 'landmark_2d_106': face.landmark_2d_106.astype(np.float32).tobytes() if face.landmark_2d_106 is not None else None,
-                'thumbnail': self._crop_face_thumbnail(img_cv, bbox),
+                'thumbnail': self._crop_face_thumbnail(img_cv, bbox) if thumbnails else None,
             })
         return {
             'face_obj': faces[0],
@@ -420,10 +454,10 @@ class FaceAnalyzer:
             return False
         return self.compute_avg_ear(lm) < self.blink_ear_threshold
 
-    def _get_crop_sharpness(self, img, bbox):
+    def _get_crop_sharpness(self, img, bbox, roi_stats=None):
         h, w = img.shape[:2]
-        y1, y2, x1, x2 = max(0, bbox[1]), min(h, bbox[3]), max(0, bbox[0]), min(w, bbox[2])
-        crop = img[y1:y2, x1:x2]
-        if crop.size == 0:
+        y1, y2, _ = slice(int(max(0, bbox[1])), int(min(h, bbox[3]))).indices(h)      # numpy slice semantics, as above
+        x1, x2, _ = slice(int(max(0, bbox[0])), int(min(w, bbox[2]))).indices(w)
+        if y2 <= y1 or x2 <= x1:                 # crop.size == 0
             return 0
-        return laplacian_var(bgr2gray(crop))
+        return (roi_stats or self._roi_numpy(img))(int(x1), int(y1), int(x2), int(y2))[0]

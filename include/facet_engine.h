@@ -233,6 +233,13 @@ int fe_cv_resize_linear_u8(fe_ctx* ctx, const uint8_t* src, int n, int h, int w,
 int fe_image_stats(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, double* stats, uint8_t* gray_out,
                    uint8_t* hsv_out);
 
+/* Laplacian statistics of m rectangular ROIs: what analyzers/face.py:160-176 (eye regions) and :272-279
+ * (face crop) compute with cv2.cvtColor(roi, BGR2GRAY) + cv2.Laplacian(gray, CV_64F).var() + np.mean(gray) per face on the CPU.
+ * rois [m][4] = x1,y1,x2,y2 (exclusive, already clipped to the image like the reference's slices); borders reflect (101) at
+ * the ROI edge. out [m][4]: sum of Laplacian, sum of squares, sum of gray, pixel count (exact integers). Empty ROIs give 0s. */
+int fe_roi_laplacian(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, int m, const int* img_index, const int* rois,
+                     double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,7 +123,8 @@ def laplacian_var(gray):
     g = gray.astype(np.float64)
     if g.size == 0:
         return 0.0
-    p = np.pad(g, 1, mode="reflect") if min(g.shape) > 1 else np.pad(g, 1, mode="edge")
+    p = np.pad(g, ((1, 1), (0, 0)), mode="reflect" if g.shape[0] > 1 else "edge")      # BORDER_REFLECT_101 per axis; a
+    p = np.pad(p, ((0, 0), (1, 1)), mode="reflect" if g.shape[1] > 1 else "edge")      # length-1 axis repeats its only sample
     lap = p[:-2, 1:-1] + p[2:, 1:-1] + p[1:-1, :-2] + p[1:-1, 2:] - 4.0 * g
     return float(lap.var())
 

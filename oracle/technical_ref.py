@@ -38,7 +38,8 @@ def bgr2hsv(img):
 
 
 def _pad101(g):
-    return np.pad(g, 1, mode="reflect") if min(g.shape) > 1 else np.pad(g, 1, mode="edge")
+    p = np.pad(g, ((1, 1), (0, 0)), mode="reflect" if g.shape[0] > 1 else "edge")      # BORDER_REFLECT_101 per axis; a length-1
+    return np.pad(p, ((0, 0), (1, 1)), mode="reflect" if g.shape[1] > 1 else "edge")   # axis repeats its only sample
 
 
 def laplacian64(gray):

@@ -126,3 +126,30 @@ def test_face_analyzer_dict_matches_reference_logic(engine, models):
     assert single["face_count"] == res[1]["face_count"] and single["face_quality"] == res[1]["face_quality"]
     fa.face_app.unload()
     assert fa.analyze_faces(None)["face_count"] == 0
+
+
+def test_roi_laplacian_matches_numpy(engine):
+    rng = np.random.default_rng(21)
+    imgs = rng.integers(0, 256, (3, 90, 140, 3), dtype=np.uint8)
+    rois, idx = [], []
+    for f in range(40):
+        x1, y1 = int(rng.integers(0, 139)), int(rng.integers(0, 89))
+        x2, y2 = int(rng.integers(x1 + 1, 141)), int(rng.integers(y1 + 1, 91))
+        rois.append([x1, y1, x2, y2]); idx.append(f % 3)
+    rois += [[5, 5, 6, 30], [5, 5, 30, 6], [7, 7, 8, 8], [0, 0, 140, 90], [10, 10, 10, 20]]     # 1-wide, 1-high, 1 pixel, full, empty
+    idx += [0, 1, 2, 0, 1]
+    st = engine.roi_laplacian(imgs, idx, rois)
+    for (x1, y1, x2, y2), i, row in zip(rois, idx, st):
+        g = face_ref.bgr2gray(imgs[i][y1:y2, x1:x2])
+        if g.size == 0:
+            assert not row.any()
+            continue
+        gg = g.astype(np.float64)
+        lap = np.zeros_like(gg)                     # explicit per-pixel reflect-101 (a length-1 axis repeats its sample)
+        r101 = lambda k, n: 0 if n == 1 else (-k if k < 0 else (2 * (n - 1) - k if k >= n else k))
+        for yy in range(gg.shape[0]):
+            for xx in range(gg.shape[1]):
+                lap[yy, xx] = (gg[r101(yy - 1, gg.shape[0]), xx] + gg[r101(yy + 1, gg.shape[0]), xx] + gg[yy, r101(xx - 1, gg.shape[1])] +
+                               gg[yy, r101(xx + 1, gg.shape[1])] - 4.0 * gg[yy, xx])
+        assert abs(face_ref.laplacian_var(g) - lap.var()) <= 1e-9 * max(1.0, lap.var())
+        assert row[0] == lap.sum() and row[1] == (lap * lap).sum() and row[2] == gg.sum() and row[3] == g.size
