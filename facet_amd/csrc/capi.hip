@@ -24,6 +24,8 @@ struct fe_ctx {
   struct CvResizeTab { int* ofs; short* coef; };
   std::map<std::tuple<int, int, int>, CvResizeTab> cvresize;   // (src, dst, clamp) -> tables
   std::vector<void*> misc_allocs;
+  float* clip_in = nullptr;  // preprocessed CLIP crops waiting for a full tower batch (ClipBatcher)
+  size_t clip_in_cap = 0;
   float* d_out = nullptr;   // persistent device staging for per-image results
   size_t d_out_cap = 0;
   float* out_buf(size_t floats) {
@@ -149,6 +151,7 @@ void fe_destroy(fe_ctx* ctx) {
   }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   for (void* q : ctx->misc_allocs) (void)hipFree(q);
+  if (ctx->clip_in) (void)hipFree(ctx->clip_in);
   delete ctx;
 }
 
@@ -687,6 +690,74 @@ int fe_samp_forward(fe_ctx* ctx, const float* x, int n, float* pattern_weights, 
 // x: fp32 NCHW [n,3,224,224] as open_clip's eval transform yields (host, or device when on_device).
 // features [n,768] un-normalised (= model.encode_image); emb_norm (nullable) = F.normalize(features);
 // aesthetic_raw (nullable, needs FE_MODEL_AESTHETIC) = aesthetic_head(features) before the (x+1)*5 clamp.
+// The ViT tower wants more images per launch than the 1024^2 models can hold in flight: its GEMMs have rows = images x 257
+// tokens in 128-row tiles x (width / 128) column tiles over 256 CUs, and a partially filled last round of workgroups costs up
+// to a third of a launch. tools/clip_mb_sweep.py: 621 img/s at 32 images per launch, ~700 at 95-127. So crops (602 KB each)
+// are collected across micro-batches and the tower runs on `chunk` of them, chunk chosen for full rounds.
+extern "C++" {
+static int clip_tower_chunk(const ClipModel& m, int n) {
+  if (n <= 40) return n;
+  const int hi = std::min(n, 128), lo = std::max(32, hi - 40), ntile = std::max(1, m.width / 128);
+  int best = hi;
+  double best_eff = 0.0;
+  for (int c = hi; c >= lo; --c) {
+    const long wgs = (((long)c * m.tokens + 127) / 128) * ntile;
+    const double eff = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
+  }
+  return best;
+}
+class ClipBatcher {
+ public:
+  ClipBatcher(fe_ctx* ctx, int n_total, int max_push, float* d_feat, float* d_norm, float* d_aes)
+      : x_(ctx), feat_(d_feat), norm_(d_norm), aes_(d_aes) {
+    const ClipModel& m = *ctx->c.clip;
+    hw_ = m.patch_size * (int)std::lround(std::sqrt((double)(m.tokens - 1)));
+    od_ = m.out_dim;
+    per_ = (size_t)hw_ * hw_ * 4;
+    chunk_ = clip_tower_chunk(m, n_total);
+    const size_t need = (size_t)(chunk_ + max_push) * per_;
+    if (ctx->clip_in_cap < need) {
+      FE_HIP(hipStreamSynchronize(ctx->c.stream));
+      if (ctx->clip_in) FE_HIP(hipFree(ctx->clip_in));
+      ctx->clip_in = nullptr; ctx->clip_in_cap = 0;
+      FE_HIP(hipMalloc((void**)&ctx->clip_in, need * sizeof(float)));
+      ctx->clip_in_cap = need;
+    }
+  }
+  // xt: dense NHWC4 crops of one micro-batch (arena memory; copied out before the arena is recycled)
+  void push(const Tensor& xt) {
+    FE_CHECK(xt.c == 4 && xt.ld == 4 && xt.h == hw_ && xt.w == hw_, "clip batcher: crop layout");
+    FE_HIP(hipMemcpyAsync(x_->clip_in + (size_t)count_ * per_, xt.p, (size_t)xt.n * per_ * sizeof(float), hipMemcpyDeviceToDevice, x_->c.stream));
+    count_ += xt.n;
+    while (count_ >= chunk_) run(chunk_);
+  }
+  void finish() {
+    while (count_ > 0) run(std::min(count_, chunk_));
+  }
+ private:
+  void run(int c) {
+    Ctx& C = x_->c;
+    const size_t mark = C.arena.mark();
+    Tensor x;
+    x.p = x_->clip_in; x.n = c; x.h = hw_; x.w = hw_; x.c = 4; x.ld = 4;
+    clip_forward(C, *C.clip, x, feat_ + (size_t)done_ * od_);
+    if (norm_) l2_normalize(C, feat_ + (size_t)done_ * od_, norm_ + (size_t)done_ * od_, c, od_);
+    if (aes_) aesthetic_forward(C, *C.aesthetic, feat_ + (size_t)done_ * od_, c, aes_ + done_);
+    C.arena.rewind(mark);
+    const int left = count_ - c;   // < chunk_ = c whenever a full chunk ran, so source and destination cannot overlap
+    if (left > 0)
+      FE_HIP(hipMemcpyAsync(x_->clip_in, x_->clip_in + (size_t)c * per_, (size_t)left * per_ * sizeof(float), hipMemcpyDeviceToDevice, C.stream));
+    done_ += c;
+    count_ = left;
+  }
+  fe_ctx* x_;
+  float *feat_, *norm_, *aes_;
+  int hw_ = 224, od_ = 768, chunk_ = 1, count_ = 0, done_ = 0;
+  size_t per_ = 0;
+};
+}  // extern "C++"
+
 int fe_clip_encode_image(fe_ctx* ctx, const float* x, int n, int on_device, float* features, float* emb_norm,
                          float* aesthetic_raw) {
   FE_API_BEGIN(ctx)
@@ -699,8 +770,9 @@ int fe_clip_encode_image(fe_ctx* ctx, const float* x, int n, int on_device, floa
   const size_t per = (size_t)3 * hw * hw;
   float* d_out = ctx->out_buf((size_t)n * (2 * od + 1));
   float* d_feat = d_out; float* d_norm = d_out + (size_t)n * od; float* d_aes = d_out + (size_t)n * 2 * od;
-  for (int i0 = 0; i0 < n; i0 += ctx->microbatch) {
-    const int nb = std::min(ctx->microbatch, n - i0);
+  const int step = clip_tower_chunk(*C.clip, n);   // inputs are already 224^2: batch the tower for full rounds of workgroups
+  for (int i0 = 0; i0 < n; i0 += step) {
+    const int nb = std::min(step, n - i0);
     C.arena.reset();
     Tensor xt;
     if (on_device) {
@@ -782,6 +854,7 @@ int fe_clip_encode_images(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, 
   const size_t per = (size_t)h * w * 3;
   float* d_out = ctx->out_buf((size_t)n * (2 * od + 1));
   float* d_feat = d_out; float* d_norm = d_out + (size_t)n * od; float* d_aes = d_out + (size_t)n * 2 * od;
+  ClipBatcher tower(ctx, n, ctx->microbatch, d_feat, emb_norm ? d_norm : nullptr, aesthetic_raw ? d_aes : nullptr);
   ImageStager st(ctx, rgb, n, per, ctx->microbatch, on_device);
   for (int k = 0; k < st.chunks(); ++k) {
     const int i0 = k * ctx->microbatch, nb = st.count(k);
@@ -789,10 +862,10 @@ int fe_clip_encode_images(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, 
     const uint8_t* d_in = st.get(k);
     Tensor xt = preprocess_square224(C, d_in, nb, h, w, FE_FILTER_BICUBIC, true, kClipMean, kClipStd, 0);
     st.done(k);   // the raw images are consumed by the resize kernels queued above
-    clip_forward(C, *C.clip, xt, d_feat + (size_t)i0 * od);
-    if (emb_norm) l2_normalize(C, d_feat + (size_t)i0 * od, d_norm + (size_t)i0 * od, nb, od);
-    if (aesthetic_raw) aesthetic_forward(C, *C.aesthetic, d_feat + (size_t)i0 * od, nb, d_aes + i0);
+    (void)i0;
+    tower.push(xt);
   }
+  tower.finish();
   if (features) FE_HIP(hipMemcpyAsync(features, d_feat, (size_t)n * od * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   if (emb_norm) FE_HIP(hipMemcpyAsync(emb_norm, d_norm, (size_t)n * od * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   if (aesthetic_raw) FE_HIP(hipMemcpyAsync(aesthetic_raw, d_aes, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, C.stream));
@@ -898,6 +971,8 @@ int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
   const bool do_topiq = C.topiq && C.topiq->has_head, do_clip = (bool)C.clip, do_samp = C.samp && C.u2netp;
   float* p_topiq = d_rec;  float* p_aes = d_rec + o_aes;  float* p_pw = d_rec + o_pw;  float* p_at = d_rec + o_at;
   float* p_sd = d_rec + o_sd;  float* p_emb = d_rec + o_emb;  float* d_feat = d_rec + o_feat;
+  std::unique_ptr<ClipBatcher> tower;
+  if (do_clip) tower = std::make_unique<ClipBatcher>(ctx, n, ctx->microbatch, d_feat, p_emb, C.aesthetic ? p_aes : nullptr);
   ImageStager st(ctx, rgb, n, per, ctx->microbatch, on_device);
   for (int k = 0; k < st.chunks(); ++k) {
     const int i0 = k * ctx->microbatch, nb = st.count(k);
@@ -913,9 +988,7 @@ int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
     if (do_clip) {
       const size_t mark = C.arena.mark();
       Tensor xt = preprocess_square224(C, d_in, nb, h, w, FE_FILTER_BICUBIC, true, kClipMean, kClipStd, 0);
-      clip_forward(C, *C.clip, xt, d_feat + (size_t)i0 * 768);
-      l2_normalize(C, d_feat + (size_t)i0 * 768, p_emb + (size_t)i0 * 768, nb, 768);
-      if (C.aesthetic) aesthetic_forward(C, *C.aesthetic, d_feat + (size_t)i0 * 768, nb, p_aes + i0);
+      tower->push(xt);   // the ViT tower runs once enough crops have gathered for full rounds of workgroups
       C.arena.rewind(mark);
     }
     if (do_samp) {
@@ -928,6 +1001,7 @@ int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
     }
     st.done(k);
   }
+  if (tower) tower->finish();
   std::vector<float> host(o_feat);
   FE_HIP(hipMemcpyAsync(host.data(), d_rec, host.size() * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipStreamSynchronize(C.stream));
