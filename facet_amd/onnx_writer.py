@@ -43,7 +43,9 @@ def _int(field, v):
     return _key(field, 0) + _varint(int(v))
 
 
-def tensor_proto(name, arr):
+def tensor_proto(name, arr, encoding="raw"):
+    """encoding: "raw" (raw_data, what torch.onnx.export writes) or "typed" (float_data / int64_data / int32_data /
+    double_data repeated fields, what some converters write; float16 goes into int32_data as bit patterns)."""
     arr = np.asarray(arr)
     shape = arr.shape                      # ascontiguousarray would turn a 0-d scalar into shape (1,)
     arr = np.ascontiguousarray(arr)
@@ -52,7 +54,18 @@ def tensor_proto(name, arr):
     out = b"".join(_int(1, d) for d in shape)
     out += _int(2, _NP2ONNX[arr.dtype])
     out += _str(8, name)
-    out += _ld(9, arr.astype(arr.dtype.newbyteorder("<")).tobytes())
+    if encoding == "raw":
+        out += _ld(9, arr.astype(arr.dtype.newbyteorder("<")).tobytes())
+    elif arr.dtype == np.float32:
+        out += _ld(4, arr.astype("<f4").tobytes())                                   # packed float_data
+    elif arr.dtype == np.float64:
+        out += _ld(10, arr.astype("<f8").tobytes())                                  # packed double_data
+    elif arr.dtype == np.int64:
+        out += _ld(7, b"".join(_varint(int(v)) for v in arr.ravel()))                 # packed int64_data
+    elif arr.dtype == np.float16:
+        out += _ld(5, b"".join(_varint(int(v)) for v in arr.view(np.uint16).ravel()))
+    else:
+        out += _ld(5, b"".join(_varint(int(v)) for v in arr.ravel()))                 # int32_data (also int8/uint8/bool)
     return out
 
 
@@ -93,10 +106,14 @@ def value_info(name, dims, elem_type=FLOAT):
     return _str(1, name) + _ld(2, _ld(1, tensor_type))
 
 
-def model(nodes, initializers, inputs, outputs, opset=11, producer="facet_amd.onnx_writer", graph_name="g"):
-    """nodes: list of node() payloads; initializers: {name: ndarray}; inputs/outputs: [(name, dims)]."""
+def model(nodes, initializers, inputs, outputs, opset=11, producer="facet_amd.onnx_writer", graph_name="g", encoding="raw",
+          list_initializers_as_inputs=False):
+    """nodes: list of node() payloads; initializers: {name: ndarray}; inputs/outputs: [(name, dims)].
+    list_initializers_as_inputs: IR < 4 files also declare every initializer as a graph input."""
     g = b"".join(_ld(1, n) for n in nodes) + _str(2, graph_name)
-    g += b"".join(_ld(5, tensor_proto(k, v)) for k, v in initializers.items())
+    g += b"".join(_ld(5, tensor_proto(k, v, encoding)) for k, v in initializers.items())
+    if list_initializers_as_inputs:
+        inputs = list(inputs) + [(k, list(np.asarray(v).shape)) for k, v in initializers.items()]
     g += b"".join(_ld(11, value_info(n, d)) for n, d in inputs)
     g += b"".join(_ld(12, value_info(n, d)) for n, d in outputs)
     m = _int(1, 6) + _str(2, producer) + _ld(7, g) + _ld(8, _str(1, "") + _int(2, opset))
@@ -159,5 +176,5 @@ class GraphBuilder:
             ins.append(self.const((self.rng.standard_normal(cout) * 0.05).astype(np.float32), "b"))
         return self.op("Gemm", ins, alpha=1.0, beta=1.0, transB=int(trans_b))
 
-    def build(self, inputs, outputs, producer="facet_amd.onnx_writer"):
-        return model(self.nodes, self.init, inputs, outputs, opset=self.opset, producer=producer)
+    def build(self, inputs, outputs, producer="facet_amd.onnx_writer", **kw):
+        return model(self.nodes, self.init, inputs, outputs, opset=self.opset, producer=producer, **kw)

@@ -109,6 +109,8 @@ def _tensor(buf):
         arr = np.frombuffer(raw, dtype=_DT[dtype]).reshape(dims)
     elif dtype == 1:
         arr = np.asarray(fl, np.float32).reshape(dims)
+    elif dtype == 10:
+        arr = np.asarray(il, np.uint16).view(np.float16).reshape(dims)
     elif dtype == 11:
         arr = np.asarray(dl, np.float64).reshape(dims)
     else:

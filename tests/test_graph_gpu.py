@@ -98,3 +98,25 @@ def test_unsupported_operator_is_reported(engine):
     engine.graph_unload(3)
     with pytest.raises(EngineError):
         engine.graph_run(3, np.zeros((1, 3, 16, 16), np.float32))
+
+
+def test_tensor_encodings_and_legacy_input_lists(engine):
+    """The same network written with raw_data, with typed repeated fields, with float16 weights and with every initializer also
+    listed as a graph input (IR < 4) must load and give the same answer (fp16: the answer of the fp16-rounded weights)."""
+    def build(dtype, **kw):
+        g = W.GraphBuilder(33)
+        y = g.relu(g.bn(g.conv("x", 3, 20, 3, 2, bias=True), 20))
+        y = g.conv(y, 20, 32, 3, 1)
+        y = g.op("Flatten", [g.op("GlobalAveragePool", [y])], axis=1)
+        y = g.gemm(y, 32, 10)
+        if dtype is not None:
+            g.init = {k: (v.astype(dtype) if v.dtype == np.float32 else v) for k, v in g.init.items()}
+        return g.build([("x", ["N", 3, 32, 48])], [(y, ["N", 10])], **kw)
+    x = np.random.default_rng(8).uniform(-1, 1, (2, 3, 32, 48)).astype(np.float32)
+    base = _check(engine, build(None), x)[0]
+    for data in (build(None, encoding="typed"), build(None, list_initializers_as_inputs=True), build(np.float64, encoding="typed"),
+                 build(np.float64)):
+        assert np.allclose(_check(engine, data, x)[0], base, rtol=1e-5, atol=1e-6)
+    half = _check(engine, build(np.float16), x)[0]
+    half_typed = _check(engine, build(np.float16, encoding="typed"), x)[0]
+    assert np.allclose(half, half_typed, rtol=1e-6, atol=1e-7) and np.abs(half - base).max() < 0.05 * np.abs(base).max()

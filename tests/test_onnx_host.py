@@ -47,3 +47,15 @@ def test_oracle_arcface_embedding_is_deterministic():
     a = onnx_ref.run(data, x)[0]
     b = onnx_ref.run(S.arcface_iresnet(layers=(1, 1, 1, 1), seed=4)[0], x)[0]
     assert a.shape == (1, 512) and np.array_equal(a, b) and np.isfinite(a).all()
+
+
+def test_alternative_encodings_parse_on_host():
+    g = W.GraphBuilder(2)
+    y = g.gemm(g.op("Flatten", [g.conv("x", 3, 8, 3, 1)], axis=1), 8 * 6 * 6, 4)
+    for kw in (dict(encoding="typed"), dict(list_initializers_as_inputs=True)):
+        data = g.build([("x", [1, 3, 6, 6])], [(y, [1, 4])], **kw)
+        p = onnx_probe(data)
+        m = onnx_ref.parse(data)
+        assert p["nodes"] == 3 and p["initializers"] == len(m["init"]) == 4 and p["input_dims"] == [1, 3, 6, 6] and m["inputs"] == ["x"]
+        for k, v in g.init.items():
+            assert np.array_equal(m["init"][k], v)
