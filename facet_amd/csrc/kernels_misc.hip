@@ -175,8 +175,54 @@ __global__ void adaptive_avgpool_kernel(const float* __restrict__ x, int ldx, fl
     y[((img * ho + oh) * wo + ow) * ldy + ch] = acc / (float)((he - hs) * (we - ws));
   }
 }
+// 4 channels per thread (16-B loads), two independent accumulators per row pair so the adds do not serialise the loads.
+// The summation order over a window stays row-major like the scalar kernel's (rows alternate between the accumulators).
+__global__ void adaptive_avgpool_vec4_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int n, int h,
+                                             int w, int c4, int ho, int wo) {
+  const size_t total = (size_t)n * ho * wo * c4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c4) * 4;
+    size_t pix = i / c4;
+    const int ow = pix % wo; pix /= wo;
+    const int oh = pix % ho;
+    const size_t img = pix / ho;
+    const int hs = (oh * h) / ho, he = ((oh + 1) * h + ho - 1) / ho;
+    const int ws = (ow * w) / wo, we = ((ow + 1) * w + wo - 1) / wo;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int iy = hs; iy < he; ++iy) {
+      const float* row = x + ((img * h + iy) * w + ws) * (size_t)ldx + ch;
+      int ix = 0;
+      const int cnt = we - ws;
+      for (; ix + 4 <= cnt; ix += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(row + (size_t)ix * ldx);
+        const float4 b = *reinterpret_cast<const float4*>(row + (size_t)(ix + 1) * ldx);
+        const float4 d = *reinterpret_cast<const float4*>(row + (size_t)(ix + 2) * ldx);
+        const float4 e = *reinterpret_cast<const float4*>(row + (size_t)(ix + 3) * ldx);
+        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+        acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
+      }
+      for (; ix < cnt; ++ix) {
+        const float4 a = *reinterpret_cast<const float4*>(row + (size_t)ix * ldx);
+        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+      }
+    }
+    const float d = (float)((he - hs) * (we - ws));
+    *reinterpret_cast<float4*>(y + ((img * ho + oh) * wo + ow) * (size_t)ldy + ch) = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+  }
+}
 void launch_adaptive_avgpool(const Tensor& x, const Tensor& y, hipStream_t s) {
   FE_CHECK(x.c == y.c && x.n == y.n, "adaptive_avgpool: shape mismatch");
+  if (x.c % 4 == 0 && x.ld % 4 == 0 && y.ld % 4 == 0 && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0) {
+    const size_t work = y.pixels() * (size_t)(y.c / 4);
+    size_t g = (work + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(adaptive_avgpool_vec4_kernel, dim3((unsigned)g), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c / 4, y.h, y.w);
+    FE_HIP(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(grid_for(y.numel())), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w);
   FE_HIP(hipGetLastError());
 }
