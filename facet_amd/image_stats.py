@@ -26,8 +26,9 @@ class ImageCache:
 
     def __init__(self, img_cv=None, engine=None, _record=None, _shape=None, _gray=None, _hsv=None, keep_planes=False):
         if _record is None:
-            if engine is None:
-                raise ValueError("ImageCache needs an Engine: the statistics are computed on the GPU")
+            if engine is None:          # reference signature ImageCache(img_cv): use the process-wide engine
+                from . import default_engine
+                engine = default_engine()
             st, g, hv = engine.image_stats(np.asarray(img_cv)[None], want_gray=keep_planes, want_hsv=keep_planes)
             _record, _shape = st[0], img_cv.shape[:2]
             _gray, _hsv = (g[0], hv[0]) if keep_planes else (None, None)
@@ -66,23 +67,42 @@ class ImageCache:
 
 class TechnicalAnalyzer:
     @staticmethod
-    def _need(cache):
+    def _need(cache, image_cv=None):
+        """The reference recomputes gray / hsv with cv2 when cache is None; here that means one GPU scan of the image."""
+        if cache is None and image_cv is not None and not isinstance(image_cv, bool):
+            return ImageCache(image_cv)
         if not isinstance(cache, ImageCache):
             raise TypeError("pass cache=ImageCache(...) built by facet_amd.image_stats (the GPU computes the statistics)")
         return cache
+
+    # -- the three cache-less conveniences of the reference (technical.py:29-36, 60-78, 118-127) ---------------------
+    @staticmethod
+    def get_sharpness(image_cv):
+        return 0 if image_cv is None else min(10.0, ImageCache(image_cv).laplacian_variance / 50.0)
+
+    @staticmethod
+    def get_color_harmony(image_cv):
+        return TechnicalAnalyzer.get_color_harmony_data(image_cv)['normalized']
+
+    @staticmethod
+    def get_exposure_score(image_cv):
+        c = ImageCache(image_cv)
+        n = float(c.height * c.width)
+        clipped = c.stats[_H][:6].sum() / n + c.stats[_H][250:].sum() / n       # gray <= 5, gray >= 250
+        return max(0, 10 - clipped * 10)
 
     @staticmethod
     def get_sharpness_data(image_cv, cache=None):
         if image_cv is None:
             return {'raw_variance': 0, 'normalized': 0}
-        v = TechnicalAnalyzer._need(cache).laplacian_variance
+        v = TechnicalAnalyzer._need(cache, image_cv).laplacian_variance
         return {'raw_variance': v, 'normalized': float(min(10.0, v / 50.0))}
 
     @staticmethod
     def get_color_harmony_data(image_cv, cache=None):
         if image_cv is None:
             return {'raw_entropy': 0, 'normalized': 0}
-        c = TechnicalAnalyzer._need(cache)
+        c = TechnicalAnalyzer._need(cache, image_cv)
         n = float(c.height * c.width)
         ent = np.log2(n) - c.stats[_CLOGC] / n if n > 0 else 0
         return {'raw_entropy': ent, 'normalized': float(min(10.0, ent * 10.0 / 15.5))}
@@ -92,7 +112,7 @@ class TechnicalAnalyzer:
         if image_cv is None:
             return {'histogram_bytes': None, 'spread': 0, 'mean_luminance': 0.5, 'bimodality': 0, 'exposure_score': 5.0,
                     'shadow_clipped': 0, 'highlight_clipped': 0, 'is_silhouette': 0}
-        c = TechnicalAnalyzer._need(cache)
+        c = TechnicalAnalyzer._need(cache, image_cv)
         counts = c.stats[_H].astype(np.float32)            # cv2.calcHist returns float32 counts
         total = counts.sum()
         dist = counts / total if total > 0 else counts
@@ -118,7 +138,7 @@ class TechnicalAnalyzer:
     def detect_monochrome(image_cv, threshold=0.1, cache=None):
         if image_cv is None:
             return {'is_monochrome': 0, 'mean_saturation': 0}
-        c = TechnicalAnalyzer._need(cache)
+        c = TechnicalAnalyzer._need(cache, image_cv)
         sat = (c.stats[_SAT] / (c.height * c.width)) / 255.0
         return {'is_monochrome': 1 if sat < threshold else 0, 'mean_saturation': round(sat, 4)}
 
@@ -126,7 +146,7 @@ class TechnicalAnalyzer:
     def get_dynamic_range(image_cv, cache=None):
         if image_cv is None:
             return {'dynamic_range_stops': 0}
-        c = TechnicalAnalyzer._need(cache)
+        c = TechnicalAnalyzer._need(cache, image_cv)
         lo, hi = c.percentile(2), c.percentile(98)
         lo = 1 if lo < 1 else lo
         return {'dynamic_range_stops': round(np.log2(max(hi, 1) / lo), 2)}
@@ -135,7 +155,7 @@ class TechnicalAnalyzer:
     def get_noise_estimate(image_cv, cache=None):
         if image_cv is None:
             return {'noise_sigma': 0}
-        c = TechnicalAnalyzer._need(cache)
+        c = TechnicalAnalyzer._need(cache, image_cv)
         sigma = c.stats[_NOISE] * np.sqrt(0.5 * np.pi) / (6 * (c.width - 2) * (c.height - 2))
         return {'noise_sigma': round(sigma, 2)}
 
@@ -143,7 +163,7 @@ class TechnicalAnalyzer:
     def get_contrast_score(image_cv, cache=None):
         if image_cv is None:
             return {'contrast_score': 0, 'percentile_contrast': 0, 'rms_contrast': 0}
-        c = TechnicalAnalyzer._need(cache)
+        c = TechnicalAnalyzer._need(cache, image_cv)
         span = (c.percentile(95) - c.percentile(5)) / 255.0
         counts, levels = c.stats[_H], np.arange(256, dtype=np.float64)
         n = counts.sum()

@@ -80,6 +80,18 @@ def test_single_image_cache_and_device_resident_batch(engine):
     engine.dev_free(d)
     assert np.array_equal(st_dev[:, :260], st_host[:, :260]) and np.allclose(st_dev[:, 260], st_host[:, 260], rtol=1e-13)
     assert np.array_equal(c.stats[:260], st_host[2, :260])
+    # cache=None: the reference converts the image on the spot; the mirror scans it on the process-wide default engine
+    assert TechnicalAnalyzer.get_noise_estimate(imgs[0], cache=None) == R.noise_estimate(R.ImageCache(imgs[0]))
     with pytest.raises(TypeError):
-        TechnicalAnalyzer.get_noise_estimate(imgs[0], cache=None)
+        TechnicalAnalyzer.get_noise_estimate(imgs[0], cache="not a cache")
     assert TechnicalAnalyzer.get_noise_estimate(None) == {'noise_sigma': 0}
+
+
+def test_cacheless_conveniences(engine):
+    img = _images("photo", 1, 80, 120, 4)[0]
+    c = R.ImageCache(img)
+    assert abs(TechnicalAnalyzer.get_sharpness(img) - min(10.0, c.laplacian_variance / 50.0)) < 1e-9
+    assert abs(TechnicalAnalyzer.get_color_harmony(img) - R.color_harmony_data(c)['normalized']) < 1e-5
+    want = max(0, 10 - (np.sum(c.gray <= 5) / c.gray.size + np.sum(c.gray >= 250) / c.gray.size) * 10)      # technical.py:118-127
+    assert abs(TechnicalAnalyzer.get_exposure_score(img) - want) < 1e-12
+    assert TechnicalAnalyzer.get_sharpness(None) == 0
