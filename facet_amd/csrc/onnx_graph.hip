@@ -98,7 +98,12 @@ void parse_tensor(Rd r, TensorData& t) {
     }
   }
   for (auto d : t.dims) FE_CHECK(d >= 0, "onnx: tensor '%s' has a negative dim", t.name.c_str());
-  const size_t n = t.numel();
+  size_t n = 1;
+  for (auto d : t.dims) {   // corrupted dims must not turn into a giant allocation
+    FE_CHECK(d == 0 || n <= ((size_t)1 << 40) / (size_t)d, "onnx: tensor '%s' has an implausible shape", t.name.c_str());
+    n *= (size_t)d;
+  }
+  FE_CHECK(n <= (size_t)1 << 32, "onnx: tensor '%s' has %zu elements", t.name.c_str(), n);
   auto need_raw = [&](size_t esz) { FE_CHECK(rawlen == n * esz, "onnx: tensor '%s' raw_data is %zu bytes, expected %zu", t.name.c_str(), rawlen, n * esz); };
   switch (t.dtype) {
     case 1:
@@ -106,13 +111,17 @@ void parse_tensor(Rd r, TensorData& t) {
       else t.f = std::move(fdata);
       break;
     case 10:
+      if (raw) need_raw(2);
+      else FE_CHECK(idata.size() == n, "onnx: f16 tensor '%s' size", t.name.c_str());
       t.f.resize(n);
-      if (raw) { need_raw(2); for (size_t k = 0; k < n; ++k) { uint16_t h; memcpy(&h, raw + 2 * k, 2); t.f[k] = half_to_float(h); } }
+      if (raw) { for (size_t k = 0; k < n; ++k) { uint16_t h; memcpy(&h, raw + 2 * k, 2); t.f[k] = half_to_float(h); } }
       else { FE_CHECK(idata.size() == n, "onnx: f16 tensor '%s' size", t.name.c_str()); for (size_t k = 0; k < n; ++k) t.f[k] = half_to_float((uint16_t)idata[k]); }
       break;
     case 11:
+      if (raw) need_raw(8);
+      else FE_CHECK(ddata.size() == n, "onnx: f64 tensor '%s' size", t.name.c_str());
       t.f.resize(n);
-      if (raw) { need_raw(8); for (size_t k = 0; k < n; ++k) { double d; memcpy(&d, raw + 8 * k, 8); t.f[k] = (float)d; } }
+      if (raw) { for (size_t k = 0; k < n; ++k) { double d; memcpy(&d, raw + 8 * k, 8); t.f[k] = (float)d; } }
       else { FE_CHECK(ddata.size() == n, "onnx: f64 tensor '%s' size", t.name.c_str()); for (size_t k = 0; k < n; ++k) t.f[k] = (float)ddata[k]; }
       break;
     case 7:

@@ -59,3 +59,24 @@ def test_alternative_encodings_parse_on_host():
         assert p["nodes"] == 3 and p["initializers"] == len(m["init"]) == 4 and p["input_dims"] == [1, 3, 6, 6] and m["inputs"] == ["x"]
         for k, v in g.init.items():
             assert np.array_equal(m["init"][k], v)
+
+
+def test_corrupted_bytes_never_crash_the_reader():
+    """Bit flips / truncations of a valid file: the host parser must answer (ok or EngineError), never fault or balloon."""
+    g = W.GraphBuilder(5)
+    y = g.relu(g.bn(g.conv("x", 3, 8, 3, 1), 8))
+    data = bytearray(g.build([("x", [1, 3, 8, 8])], [(y, [1, 8, 8, 8])]))
+    rng = np.random.default_rng(0)
+    outcomes = {"ok": 0, "rejected": 0}
+    for trial in range(300):
+        bad = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            bad[int(rng.integers(0, len(bad)))] = int(rng.integers(0, 256))
+        if trial % 5 == 0:
+            bad = bad[: int(rng.integers(1, len(bad)))]
+        try:
+            onnx_probe(bytes(bad))
+            outcomes["ok"] += 1
+        except EngineError:
+            outcomes["rejected"] += 1
+    assert outcomes["ok"] + outcomes["rejected"] == 300 and outcomes["rejected"] > 0
