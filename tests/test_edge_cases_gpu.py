@@ -90,3 +90,56 @@ def test_topiq_long_edge_cap_matches_reference_preprocessing(engine):
     a = engine.topiq_score(big)
     b = engine.topiq_score(small)
     assert np.array_equal(a, b)
+
+
+# ---- face / statistics entry points: empty results, degenerate shapes, misuse ------------------------------------------------
+def test_face_analyze_without_detections_and_without_models(engine):
+    from facet_amd import synthetic_onnx as S
+    from facet_amd._lib import EngineError, FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC
+    imgs = np.random.default_rng(0).integers(0, 256, (2, 96, 160, 3), dtype=np.uint8)
+    for slot in (FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC):
+        if engine.graph_loaded(slot):
+            engine.graph_unload(slot)
+    with pytest.raises(EngineError, match="no graph loaded"):
+        engine.face_analyze(imgs, (160, 160))
+    engine.graph_load(FE_GRAPH_FACE_DET, S.scrfd_like(seed=12, size=160)[0])
+    faces, counts, mask = engine.face_analyze(imgs, (160, 160), det_thresh=0.999)      # nothing passes: empty, not an error
+    assert mask == 1 and counts.tolist() == [0, 0] and not faces.any()
+    faces, counts, mask = engine.face_analyze(imgs, (160, 160), det_thresh=0.5, max_faces=4)   # detector only: boxes + keypoints, no more
+    assert mask == 1 and counts.min() > 0
+    k = min(int(counts[0]), 4)
+    assert np.isfinite(faces).all() and faces[0, :k, 4].min() >= 0.5 and not faces[0, :k, 15:].any()
+    assert (np.diff(faces[0, :k, 4]) <= 0).all()                                        # best score first
+    with pytest.raises(EngineError):
+        engine.face_analyze(imgs, (100, 100))                                           # det size must be a multiple of 32
+    engine.graph_unload(FE_GRAPH_FACE_DET)
+
+
+def test_crops_and_rois_edge_cases(engine):
+    from facet_amd._lib import EngineError, FE_GRAPH_FACE_REC
+    imgs = np.random.default_rng(1).integers(0, 256, (1, 40, 50, 3), dtype=np.uint8)
+    out, crops = engine.face_crops_run(FE_GRAPH_FACE_REC, imgs, np.zeros(0, np.int32), np.zeros((0, 2, 3)), 112, 0.0, 1.0, out_dim=0, want_crops=True)
+    assert crops.shape == (0, 112, 112, 3)
+    # a crop entirely outside the image is black (borderValue = 0); a singular matrix must not fault
+    M = np.array([[[1.0, 0, 500.0], [0, 1.0, 500.0]], [[0.0, 0, 0], [0, 0.0, 0]]])
+    _, crops = engine.face_crops_run(FE_GRAPH_FACE_REC, imgs, [0, 0], M, 112, 0.0, 1.0, out_dim=0, want_crops=True)
+    assert not crops[0].any() and crops.shape == (2, 112, 112, 3)
+    with pytest.raises(EngineError):
+        engine.face_crops_run(FE_GRAPH_FACE_REC, imgs, [3], M[:1], 112, 0.0, 1.0, out_dim=0, want_crops=True)      # image index out of range
+    assert engine.roi_laplacian(imgs, np.zeros(0, np.int32), np.zeros((0, 4), np.int32)).shape == (0, 4)
+    with pytest.raises(EngineError):
+        engine.roi_laplacian(imgs, [0], [[0, 0, 51, 40]])                                                            # leaves the image
+
+
+@pytest.mark.parametrize("shape", [(1, 37), (29, 1), (1, 1), (2, 2), (5, 1024)])
+def test_image_stats_degenerate_shapes(engine, shape):
+    from oracle import technical_ref as R
+    imgs = np.random.default_rng(shape[0] * 7 + shape[1]).integers(0, 256, (2, shape[0], shape[1], 3), dtype=np.uint8)
+    st, gray, hsv = engine.image_stats(imgs, want_gray=True, want_hsv=True)
+    for i in range(2):
+        c = R.ImageCache(imgs[i])
+        assert np.array_equal(gray[i], c.gray) and np.array_equal(hsv[i], c.hsv)
+        lap = R.laplacian64(c.gray)
+        assert st[i, 256] == lap.sum() and st[i, 257] == (lap * lap).sum()
+        assert st[i, 258] == np.abs(R.filter2d_immerkaer(c.gray.astype(np.float64))).sum()
+        assert st[i, :256].sum() == shape[0] * shape[1]
