@@ -10,6 +10,6 @@ path = os.path.join(root, "profiles", "r01_traffic.json")
 out = json.load(open(path)) if os.path.exists(path) else {}
 out[workload] = {"fetch_kb_per_image": total(fd, "FETCH_SIZE") / n, "write_kb_per_image": total(wd, "WRITE_SIZE") / n,
                  "image_size": hw, "images_in_run": n,
-                 "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 --batch 32 --cpu-sample 0"}
+                 "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --workload {workload} --steps 1 --warmup 1 --batch 32 --cpu-sample 0"}
 json.dump(out, open(path, "w"), indent=1)
 print(out[workload])
