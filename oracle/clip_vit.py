@@ -8,6 +8,8 @@ pretrained='laion2b_s32b_b82k')` (models/model_manager.py:140-143, processing/sc
 VisionTransformer [DEP-KNOWLEDGE]: conv1 (14x14/14, no bias), class_embedding, positional_embedding [257,1024],
 ln_pre, 24 residual blocks {ln_1, nn.MultiheadAttention(1024, 16), ln_2, mlp c_fc-GELU(erf)-c_proj}, ln_post on
 the class token, `@ proj` [1024,768]. State-dict keys are open_clip's (`visual.*`).
+Second opinion: tests/test_oracle_second_opinion.py loads the same weights into HuggingFace transformers' independent CLIP
+implementation (installed offline) and gets the same embeddings for both towers.
 The aesthetic head IS in-tree: Linear(768,256)-ReLU-Linear(256,1) (processing/scorer.py:579-583), score =
 clamp((x+1)*5, 0, 10) (:669) -> pinned by reading that definition.
 """

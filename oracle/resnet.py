@@ -3,6 +3,7 @@
 ResNet-50: timm `resnet50` with features_only=True as pyiqa's CFANet builds it for topiq_nr
 (reference call site models/pyiqa_scorer.py:108-111,212; architecture [DEP-KNOWLEDGE]: 7x7/2 stem, 3x3/2
 maxpool, bottlenecks 3-4-6-3 with the stride on the 3x3 conv, outputs after stem-ReLU and each layer).
+Second opinion for ResNet-50: equal to transformers' ResNetModel on all five outputs (tests/test_oracle_second_opinion.py).
 ResNet-18: torchvision `resnet18` children[:-2] exactly as reference models/samp_net.py:652-662 wires it
 (nn.Sequential numbering 0=conv1 1=bn1 2=relu 3=maxpool 4..7=layer1..4) -> parity unpinned for the class
 itself (torchvision is not installed), pinned end-to-end through SAMPNet's golden vectors.
