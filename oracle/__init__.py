@@ -12,5 +12,11 @@ Pinning status (see DESIGN.md "Oracle"):
   * ResNet-50 backbone + CFANet head (oracle/topiq.py), CLIP ViT-L/14 (oracle/clip_vit.py): the arithmetic
     lives in pyiqa / timm / open_clip, which are NOT vendored in the reference and not installed here
     (requirements.txt:8,36, lower-bound pins only); the reference holds no tests or fixtures for them.
-    These restate the published architectures -> "parity unpinned".
+    These restate the published architectures -> "parity unpinned" against those packages. Second opinion (not the
+    reference's code path, but independent code): the ResNet-50 pyramid and both CLIP towers equal HuggingFace
+    transformers' implementations with the same weights (tests/test_oracle_second_opinion.py); the CFANet head has none.
+  * ONNX graph evaluation (oracle/onnx_ref.py), face pre/post-processing (oracle/face_ref.py), technical metrics
+    (oracle/technical_ref.py): restate ONNX operator semantics / insightface / OpenCV fixed-point arithmetic
+    [DEP-KNOWLEDGE]; onnxruntime, insightface, cv2 and the buffalo_l files are absent -> "parity unpinned"; the OpenCV
+    pieces are held to known answers in tests/test_cv_semantics.py.
 """
