@@ -74,6 +74,20 @@ ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>
           tp[(size_t)(t * c.Cout + co) * c.KpT + ci] = w.data[(((size_t)co * c.Cin + ci) * c.KH + t / c.KW) * c.KW + t % c.KW];
     c.wtap = dw.upload(tp);
   }
+  if (c.CinPad == 4 && c.KH == c.KW && (c.KH == 7 || c.KH == 3) && (c.Cout == 32 || c.Cout == 64)) {
+    // stem layout; a 4th input channel must be all-zero weights (padding), the stem kernel never multiplies it
+    bool ch3_zero = true;
+    const int taps = c.KH * c.KW, taps2 = (taps + 1) & ~1;
+    for (int co = 0; co < c.Cout && c.Cin == 4; ++co)
+      for (int t = 0; t < taps; ++t) ch3_zero = ch3_zero && w.data[((size_t)co * c.Cin + 3) * taps + t] == 0.f;
+    if (ch3_zero) {
+      std::vector<float> st((size_t)taps2 * c.Cout * 4, 0.f);
+      for (int co = 0; co < c.Cout; ++co)
+        for (int ci = 0; ci < c.Cin && ci < 3; ++ci)
+          for (int t = 0; t < taps; ++t) st[((size_t)t * c.Cout + co) * 4 + ci] = w.data[((size_t)co * c.Cin + ci) * taps + t];
+      c.wstem = dw.upload(st);
+    }
+  }
   if (scale) c.scale = dw.upload(*scale);
   if (shift) c.shift = dw.upload(*shift);
   return c;
@@ -182,11 +196,21 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
     c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout);
     return;
   }
+  // dedicated stem kernel (patch + weights resident in LDS) for 7x7/2 and 3x3/1|2 first layers; falls back otherwise
+  static const bool no_stem = getenv("FE_NO_STEM") != nullptr;
+  const bool stem = w.wstem && !no_stem && p.variant == 0 && o.sh == o.sw && o.ph == w.KH / 2 && o.pw == w.KW / 2 && o.dh == 1 && o.dw == 1 && !o.res &&
+                    !o.gate && (o.act == ACT_NONE || o.act == ACT_RELU || o.act == ACT_PRELU);
+  auto launch = [&]() {
+    if (stem && launch_stem(x.p, x.ld, x.n, x.h, x.w, w.wstem, w.scale, w.shift, w.slope, w.Cout, w.KH, o.sh,
+                            o.act == ACT_RELU ? 1 : (o.act == ACT_PRELU ? 2 : 0), y.p, y.ld, y.h, y.w, c.stream))
+      return;
+    launch_conv(p, c.stream);
+  };
   if (c.profile) {
     hipEvent_t e0, e1;
     FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
     FE_HIP(hipEventRecord(e0, c.stream));
-    launch_conv(p, c.stream);
+    launch();
     FE_HIP(hipEventRecord(e1, c.stream));
     FE_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -197,7 +221,7 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
     double bytes = 4.0 * ((double)x.pixels() * x.c + (double)y.pixels() * y.c * (o.res ? 2 : 1) + (double)w.Cout * w.K);
     c.timings.push_back({nm, 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout), bytes, ms});
   } else {
-    launch_conv(p, c.stream);
+    launch();
   }
   c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout);
 }
@@ -321,11 +345,12 @@ static void raw_gemm(Ctx& c, ConvParams& p, double flops) {
   p.Kp = (p.K + CONV_KALIGN - 1) / CONV_KALIGN * CONV_KALIGN;
   p.Cin = p.K;
   FE_CHECK(p.xs1 % 4 == 0 && p.xs2 % 4 == 0 && p.ws1 % 4 == 0 && p.ws2 % 4 == 0, "raw_gemm: batch strides must keep 16-B alignment");
+  auto launch = [&]() { launch_conv(p, c.stream); };
   if (c.profile) {
     hipEvent_t e0, e1;
     FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
     FE_HIP(hipEventRecord(e0, c.stream));
-    launch_conv(p, c.stream);
+    launch();
     FE_HIP(hipEventRecord(e1, c.stream));
     FE_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

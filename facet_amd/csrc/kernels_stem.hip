@@ -1,0 +1,150 @@
+// Stem convolutions (3(+1 zero) input channels -> 32 or 64 output channels): 7x7 stride 2 = the first layer of ResNet-50 (TOPIQ,
+// pyiqa/timm resnet50 conv1) and ResNet-18 (SAMP-Net, reference models/samp_net.py:652-662); 3x3 stride 1 / 2 = the first
+// layer of the face graphs (ArcFace IResNet, SCRFD). With Cin = 4 the generic
+// implicit-GEMM kernel spends its time gathering 16-byte taps from HBM/L2 (K = 196 -> 59 TFLOP/s at 1024^2); here the input
+// patch of an 8x32 output tile (21 x 69 pixels x 16 B = 23 KB) and the whole weight tensor (Cout x 50 taps x 16 B) sit in LDS
+// and the MFMA operands are read straight out of them:
+//   * one ds_read_b128 = the 4 channels of one tap of one pixel = the A operand of the MFMAs of that tap (k-permutation:
+//     lanes 0-31 feed tap 2p, lanes 32-63 tap 2p+1 of a tap pair); the zero 4th channel is skipped -> 3 MFMAs per tap pair,
+//     K_eff = 150 for 147 algorithmic,
+//   * operands are swapped (weights as A, pixels as B) so every lane ends up holding 4 consecutive output channels of ITS
+//     pixel: the epilogue stores float4 rows directly from the accumulators, no LDS transpose.
+#include "fe_common.h"
+
+namespace fe {
+
+typedef float stem_f32x16 __attribute__((ext_vector_type(16)));
+typedef float stem_v4f __attribute__((ext_vector_type(4)));
+
+struct StemParams {
+  const float* x; int ldx;      // NHWC fp32, >= 4 floats per pixel (channel 3 is ignored)
+  const float* w;               // [TAPS2][Cout][4]: tap-major so the 32 lanes of a fragment read consecutive 16-B words; channel 3 and the padding tap are zero
+  const float* scale; const float* shift;
+  float* y; int ldy;
+  const float* slope;           // PReLU slopes (act == 2)
+  int N, H, W, Ho, Wo, Cout, act;   // act: 0 none, 1 relu, 2 prelu
+};
+
+constexpr int STEM_TH = 8, STEM_TW = 32;
+
+template <int TN, int STEM_K, int STEM_S>   // TN = Cout / 32; square kernel STEM_K, stride STEM_S, padding STEM_K / 2
+__global__ __launch_bounds__(256, 2) void stem_kernel(StemParams p) {
+  constexpr int STEM_P = STEM_K / 2;
+  constexpr int STEM_PH = (STEM_TH - 1) * STEM_S + STEM_K;   // 7x7/2: 21 patch rows
+  constexpr int STEM_PW = (STEM_TW - 1) * STEM_S + STEM_K;   // 7x7/2: 69 patch columns
+  constexpr int STEM_TAPS2 = (STEM_K * STEM_K + 1) & ~1;     // taps padded to an even count (49 -> 50)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                                  // [PH][PW][4]
+  float* wl = smem + STEM_PH * STEM_PW * 4;             // [TAPS2][TN*32][4]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int ox0 = blockIdx.x * STEM_TW, oy0 = blockIdx.y * STEM_TH, img = blockIdx.z;
+
+  // ---- stage the input patch (zero outside the image = the convolution's zero padding) and the weights --------------
+  const int iy0 = oy0 * STEM_S - STEM_P, ix0 = ox0 * STEM_S - STEM_P;
+  for (int i = t; i < STEM_PH * STEM_PW; i += 256) {
+    const int py = i / STEM_PW, px = i - py * STEM_PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+      v = *reinterpret_cast<const float4*>(p.x + (((size_t)img * p.H + iy) * p.W + ix) * p.ldx);
+    v.w = 0.f;
+    *reinterpret_cast<float4*>(patch + (size_t)i * 4) = v;
+  }
+  for (int i = t; i < TN * 32 * STEM_TAPS2; i += 256)
+    *reinterpret_cast<float4*>(wl + (size_t)i * 4) = *reinterpret_cast<const float4*>(p.w + (size_t)i * 4);
+  __syncthreads();
+
+  // ---- MFMA over 25 tap pairs; wave w owns output rows 2w, 2w+1 of the tile (two 32-pixel B tiles) ----------------------
+  stem_f32x16 acc[TN][2];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+  const float* prow[2] = {patch + ((size_t)((2 * wave + 0) * STEM_S) * STEM_PW + r * STEM_S) * 4,
+                          patch + ((size_t)((2 * wave + 1) * STEM_S) * STEM_PW + r * STEM_S) * 4};
+#pragma unroll
+  for (int pr = 0; pr < STEM_TAPS2 / 2; ++pr) {
+    int tap = 2 * pr + h;
+    int ky = tap / STEM_K, kx = tap - ky * STEM_K;
+    if (tap >= STEM_K * STEM_K) { ky = 0; kx = 0; }      // padding tap: any valid address, its weights are zero
+    const int poff = (ky * STEM_PW + kx) * 4;
+    stem_v4f a[TN], b[2];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) a[j] = *reinterpret_cast<const stem_v4f*>(wl + ((size_t)tap * (TN * 32) + j * 32 + r) * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = *reinterpret_cast<const stem_v4f*>(prow[i] + poff);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b[i].x, acc[j][i], 0, 0, 0);
+        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b[i].y, acc[j][i], 0, 0, 0);
+        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b[i].z, acc[j][i], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue: D[row = cout][col = pixel]; lane (r, h) holds couts (e&3) + 8(e>>2) + 4h of pixel r --------------------
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oy = oy0 + 2 * wave + i, ox = ox0 + r;
+    if (oy >= p.Ho || ox >= p.Wo) continue;
+    float* dst = p.y + (((size_t)img * p.Ho + oy) * p.Wo + ox) * p.ldy;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = j * 32 + 8 * g + 4 * h;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
+        if (p.shift) sf = *reinterpret_cast<const float4*>(p.shift + co);
+        float4 v = make_float4(acc[j][i][4 * g] * sc.x + sf.x, acc[j][i][4 * g + 1] * sc.y + sf.y, acc[j][i][4 * g + 2] * sc.z + sf.z,
+                               acc[j][i][4 * g + 3] * sc.w + sf.w);
+        if (p.act == 1) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+        else if (p.act == 2) {
+          const float4 sl = *reinterpret_cast<const float4*>(p.slope + co);
+          v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y; v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+        }
+        *reinterpret_cast<float4*>(dst + co) = v;
+      }
+  }
+}
+
+template <int TN, int K, int S>
+static void launch_stem_t(const StemParams& p, hipStream_t s) {
+  constexpr int PH = (STEM_TH - 1) * S + K, PW = (STEM_TW - 1) * S + K, T2 = (K * K + 1) & ~1;
+  constexpr size_t lds = ((size_t)PH * PW * 4 + (size_t)TN * 32 * T2 * 4) * sizeof(float);
+  static bool attr = false;
+  if (!attr) { FE_HIP(hipFuncSetAttribute((const void*)stem_kernel<TN, K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  const dim3 grid((p.Wo + STEM_TW - 1) / STEM_TW, (p.Ho + STEM_TH - 1) / STEM_TH, p.N);
+  hipLaunchKernelGGL((stem_kernel<TN, K, S>), grid, dim3(256), lds, s, p);
+  FE_HIP(hipGetLastError());
+}
+
+// wstem: [taps padded to even][Cout][4]; Cout 32 or 64; (k, stride) one of (7,2) (3,1) (3,2), padding k/2; act 0 none / 1 relu /
+// 2 prelu(slope). Returns false when the shape is not one of these (the caller falls back to the generic kernel).
+bool launch_stem(const float* x, int ldx, int N, int H, int W, const float* wstem, const float* scale, const float* shift, const float* slope,
+                 int Cout, int k, int stride, int act, float* y, int ldy, int Ho, int Wo, hipStream_t s) {
+  const int pad = k / 2;
+  if (!(Cout == 32 || Cout == 64) || ldx < 4 || ldx % 4 || ldy % 4 || Ho != (H + 2 * pad - k) / stride + 1 || Wo != (W + 2 * pad - k) / stride + 1 ||
+      (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wstem) & 15) || (act == 2 && !slope) || act < 0 || act > 2)
+    return false;
+  StemParams p{x, ldx, wstem, scale, shift, y, ldy, slope, N, H, W, Ho, Wo, Cout, act};
+  const int key = k * 10 + stride;
+  if (Cout == 64) {
+    if (key == 72) launch_stem_t<2, 7, 2>(p, s);
+    else if (key == 31) launch_stem_t<2, 3, 1>(p, s);
+    else if (key == 32) launch_stem_t<2, 3, 2>(p, s);
+    else return false;
+  } else {
+    if (key == 72) launch_stem_t<1, 7, 2>(p, s);
+    else if (key == 31) launch_stem_t<1, 3, 1>(p, s);
+    else if (key == 32) launch_stem_t<1, 3, 2>(p, s);
+    else return false;
+  }
+  return true;
+}
+
+}  // namespace fe

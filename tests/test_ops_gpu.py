@@ -127,3 +127,33 @@ def test_conv_tile_variants_agree(engine, variant):
             _close(got, ref.numpy())
     finally:
         engine.set_conv_variant(0)
+
+
+@pytest.mark.parametrize("cout,hw,act", [(64, (45, 77), "relu"), (32, (64, 64), None), (64, (7, 9), "relu"), (64, (130, 33), None)])
+def test_stem7x7_kernel_matches_torch(engine, cout, hw, act):
+    """7x7 / stride 2 / pad 3 / Cin 3 takes the LDS-resident stem kernel (kernels_stem.hip); ragged tiles on every border.
+    Tolerance 2e-4 of max-abs like the other conv tests."""
+    rng = np.random.default_rng(cout + hw[0])
+    x = rng.standard_normal((2, 3, hw[0], hw[1])).astype(np.float32)
+    w = (rng.standard_normal((cout, 3, 7, 7)) * 0.1).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    got = engine.conv2d(x, w, scale=sc, shift=sh, stride=2, pad=3, act=act)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), stride=2, padding=3) * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1)
+    if act == "relu":
+        ref = F.relu(ref)
+    ref = ref.numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("cout,stride,hw", [(64, 1, (40, 50)), (32, 2, (61, 37)), (64, 2, (16, 16)), (32, 1, (9, 70))])
+def test_stem3x3_kernel_matches_torch(engine, cout, stride, hw):
+    """3x3 / pad 1 / Cin 3 first layers (face graphs) take the same LDS-resident stem kernel."""
+    rng = np.random.default_rng(cout * stride + hw[1])
+    x = rng.standard_normal((2, 3, hw[0], hw[1])).astype(np.float32)
+    w = (rng.standard_normal((cout, 3, 3, 3)) * 0.2).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    got = engine.conv2d(x, w, shift=sh, stride=stride, pad=1, act="relu")
+    ref = F.relu(F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(sh), stride=stride, padding=1)).numpy()
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
