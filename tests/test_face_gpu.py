@@ -12,6 +12,8 @@ from facet_amd._lib import FE_GRAPH_FACE_REC
 from facet_amd.face import ARCFACE_DST, FaceAnalyzer, FaceEngine, similarity_from_5pts
 from oracle import face_ref
 
+from conftest import assert_int_boxes_match
+
 pytestmark = pytest.mark.gpu
 
 
@@ -62,7 +64,7 @@ def test_detect_matches_oracle(engine, models):
             assert det_g.shape == det_w.shape and det_w.shape[0] > 0
             assert np.abs(det_g[:, 4] - det_w[:, 4]).max() < 1e-4
             assert np.abs(det_g[:, :4] - det_w[:, :4]).max() < 2e-2 and np.abs(kps_g - kps_w).max() < 2e-2
-            assert np.array_equal(det_g[:, :4].astype(int), det_w[:, :4].astype(int))
+            assert_int_boxes_match(det_g[:, :4], det_w[:, :4])
     fe.unload()
 
 
@@ -76,7 +78,7 @@ def test_face_analysis_end_to_end(engine, models):
         want = face_ref.face_analysis_get({"det": ref_models["det"]}, imgs[i], (320, 320))
         assert len(got[i]) == len(want) > 0
         for g, w in zip(got[i], want):
-            assert np.array_equal(g.bbox.astype(int), w["bbox"].astype(int))
+            assert_int_boxes_match(g.bbox, w["bbox"])
         # Crops are cut at 1/32-pixel fixed point, so a 1e-5 px difference in a box (GPU vs CPU detector arithmetic) moves a few
         # percent of the crop's samples by one sub-pixel step; on noise images that alone shifts landmarks by ~1e-3. The crop ->
         # network -> back-projection chain is therefore checked from the SAME boxes / keypoints (the product's).
