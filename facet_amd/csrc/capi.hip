@@ -26,6 +26,8 @@ struct fe_ctx {
   std::vector<void*> misc_allocs;
   float* clip_in = nullptr;  // preprocessed CLIP crops waiting for a full tower batch (ClipBatcher)
   size_t clip_in_cap = 0;
+  float* samp_in = nullptr;  // same for the SAMP-Net / U2-Net-P crops (SampBatcher)
+  size_t samp_in_cap = 0;
   float* d_out = nullptr;   // persistent device staging for per-image results
   size_t d_out_cap = 0;
   float* out_buf(size_t floats) {
@@ -152,6 +154,7 @@ void fe_destroy(fe_ctx* ctx) {
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   for (void* q : ctx->misc_allocs) (void)hipFree(q);
   if (ctx->clip_in) (void)hipFree(ctx->clip_in);
+  if (ctx->samp_in) (void)hipFree(ctx->samp_in);
   delete ctx;
 }
 
@@ -756,6 +759,55 @@ class ClipBatcher {
   int hw_ = 224, od_ = 768, chunk_ = 1, count_ = 0, done_ = 0;
   size_t per_ = 0;
 };
+// SAMP-Net + U2-Net-P see 224^2 crops too, and most of their ~130 convolutions run on 7x7 .. 56x56 maps: at 32 images per launch
+// they are launch- and tile-quantisation-bound (tools/samp_mb_sweep.py: 2216 img/s at 32 per launch, 2903 at 128). Crops are
+// collected across micro-batches like the CLIP ones; the chunk is bounded by what the arena can hold (~150 MB per image).
+class SampBatcher {
+ public:
+  SampBatcher(fe_ctx* ctx, int n_total, int max_push, float* pw, float* at, float* sd) : x_(ctx), pw_(pw), at_(at), sd_(sd) {
+    const size_t room = ctx->c.arena.capacity() > ((size_t)8 << 30) ? ctx->c.arena.capacity() - ((size_t)8 << 30) : ctx->c.arena.capacity() / 4;
+    const int fit = (int)std::min<size_t>(128, std::max<size_t>(1, room / ((size_t)150 << 20)));
+    chunk_ = std::max(1, std::min(n_total, std::max(fit, std::min(max_push, 32))));
+    per_ = (size_t)224 * 224 * 4;
+    const size_t need = (size_t)(chunk_ + max_push) * per_;
+    if (ctx->samp_in_cap < need) {
+      FE_HIP(hipStreamSynchronize(ctx->c.stream));
+      if (ctx->samp_in) FE_HIP(hipFree(ctx->samp_in));
+      ctx->samp_in = nullptr; ctx->samp_in_cap = 0;
+      FE_HIP(hipMalloc((void**)&ctx->samp_in, need * sizeof(float)));
+      ctx->samp_in_cap = need;
+    }
+  }
+  void push(const Tensor& xt) {
+    FE_CHECK(xt.c == 4 && xt.ld == 4 && xt.h == 224 && xt.w == 224, "samp batcher: crop layout");
+    FE_HIP(hipMemcpyAsync(x_->samp_in + (size_t)count_ * per_, xt.p, (size_t)xt.n * per_ * sizeof(float), hipMemcpyDeviceToDevice, x_->c.stream));
+    count_ += xt.n;
+    while (count_ >= chunk_) run(chunk_);
+  }
+  void finish() {
+    while (count_ > 0) run(std::min(count_, chunk_));
+  }
+ private:
+  void run(int c) {
+    Ctx& C = x_->c;
+    const size_t mark = C.arena.mark();
+    Tensor x;
+    x.p = x_->samp_in; x.n = c; x.h = 224; x.w = 224; x.c = 4; x.ld = 4;
+    Tensor sal = C.arena.tensor(c, 224, 224, 1);
+    u2netp_forward(C, *C.u2netp, x, sal);
+    sampnet_forward(C, *C.samp, x, sal, pw_ + (size_t)done_ * 8, at_ + (size_t)done_ * 6, sd_ + (size_t)done_ * 5);
+    C.arena.rewind(mark);
+    const int left = count_ - c;
+    if (left > 0)
+      FE_HIP(hipMemcpyAsync(x_->samp_in, x_->samp_in + (size_t)c * per_, (size_t)left * per_ * sizeof(float), hipMemcpyDeviceToDevice, C.stream));
+    done_ += c;
+    count_ = left;
+  }
+  fe_ctx* x_;
+  float *pw_, *at_, *sd_;
+  int chunk_ = 1, count_ = 0, done_ = 0;
+  size_t per_ = 0;
+};
 }  // extern "C++"
 
 int fe_clip_encode_image(fe_ctx* ctx, const float* x, int n, int on_device, float* features, float* emb_norm,
@@ -883,18 +935,17 @@ int fe_samp_score_images(fe_ctx* ctx, const uint8_t* img, int n, int h, int w, i
   FE_CHECK(img && n > 0 && pattern_weights && attributes && score_dist, "bad arguments");
   const size_t per = (size_t)h * w * 3;
   float* d_out = ctx->out_buf((size_t)n * 19);
+  SampBatcher batch(ctx, n, ctx->microbatch, d_out, d_out + (size_t)n * 8, d_out + (size_t)n * 14);
   ImageStager st(ctx, img, n, per, ctx->microbatch, on_device);
   for (int k = 0; k < st.chunks(); ++k) {
-    const int i0 = k * ctx->microbatch, nb = st.count(k);
+    const int nb = st.count(k);
     C.arena.reset();
     const uint8_t* d_in = st.get(k);
     Tensor xt = preprocess_square224(C, d_in, nb, h, w, FE_FILTER_BILINEAR, false, kImagenetMean, kImagenetStd, bgr);
     st.done(k);
-    Tensor sal = C.arena.tensor(nb, 224, 224, 1);
-    u2netp_forward(C, *C.u2netp, xt, sal);
-    sampnet_forward(C, *C.samp, xt, sal, d_out + (size_t)i0 * 8, d_out + (size_t)n * 8 + (size_t)i0 * 6,
-                    d_out + (size_t)n * 14 + (size_t)i0 * 5);
+    batch.push(xt);
   }
+  batch.finish();
   FE_HIP(hipMemcpyAsync(pattern_weights, d_out, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipMemcpyAsync(attributes, d_out + (size_t)n * 8, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipMemcpyAsync(score_dist, d_out + (size_t)n * 14, (size_t)n * 5 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
@@ -973,6 +1024,8 @@ int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
   float* p_sd = d_rec + o_sd;  float* p_emb = d_rec + o_emb;  float* d_feat = d_rec + o_feat;
   std::unique_ptr<ClipBatcher> tower;
   if (do_clip) tower = std::make_unique<ClipBatcher>(ctx, n, ctx->microbatch, d_feat, p_emb, C.aesthetic ? p_aes : nullptr);
+  std::unique_ptr<SampBatcher> samp;
+  if (do_samp) samp = std::make_unique<SampBatcher>(ctx, n, ctx->microbatch, p_pw, p_at, p_sd);
   ImageStager st(ctx, rgb, n, per, ctx->microbatch, on_device);
   for (int k = 0; k < st.chunks(); ++k) {
     const int i0 = k * ctx->microbatch, nb = st.count(k);
@@ -994,14 +1047,13 @@ int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
     if (do_samp) {
       const size_t mark = C.arena.mark();
       Tensor xt = preprocess_square224(C, d_in, nb, h, w, FE_FILTER_BILINEAR, false, kImagenetMean, kImagenetStd, 0);
-      Tensor sal = C.arena.tensor(nb, 224, 224, 1);
-      u2netp_forward(C, *C.u2netp, xt, sal);
-      sampnet_forward(C, *C.samp, xt, sal, p_pw + (size_t)i0 * 8, p_at + (size_t)i0 * 6, p_sd + (size_t)i0 * 5);
+      samp->push(xt);    // U2-Net-P + SAMP-Net run once enough crops have gathered
       C.arena.rewind(mark);
     }
     st.done(k);
   }
   if (tower) tower->finish();
+  if (samp) samp->finish();
   std::vector<float> host(o_feat);
   FE_HIP(hipMemcpyAsync(host.data(), d_rec, host.size() * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipStreamSynchronize(C.stream));
