@@ -212,6 +212,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
+    # Per-launch view of the dominant kernel family (rank 0, after the timed region): one micro-batch with a HIP event pair
+    # around every contraction launch (engine profile mode; the per-launch sync makes it slightly pessimistic). The averages
+    # are what `rocprofv3 --kernel-trace --stats` reports for conv_dma_kernel (profiles/r01_kernel_stats_bench_b64_final.csv).
+    per_launch = None
+    if rank == 0 and args.workload == "topiq":
+        nb = min(B, args.microbatch)
+        eng.profile_enable(True)
+        eng.topiq_score((d_imgs, nb, HW, HW))
+        recs = [r for r in eng.profile_records() if r["ms"] > 0]
+        eng.profile_enable(False)
+        if recs:
+            tot_ms = sum(r["ms"] for r in recs)
+            tot_fl = sum(r["flops"] for r in recs)
+            per_launch = {"launches": len(recs), "avg_us": round(tot_ms / len(recs) * 1e3, 1), "images": nb,
+                          "achieved": round(tot_fl / tot_ms / 1e9, 2), "frac": round(tot_fl / tot_ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
+                          "note": "contraction launches only (conv_dma_kernel / conv_igemm_kernel / stem_kernel), algorithmic FLOPs / summed launch durations"}
+
     if rank == 0:
         # HBM traffic of the same workload from the PMC passes (profiles/r01_traffic.json; collected with rocprofv3 --pmc
         # FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this script, gfx950 correction: FETCH_SIZE counts 64 B per
@@ -247,7 +264,7 @@ def main():
                          "traffic_unit": "bytes per step per GPU (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
                          "kernel": "conv_dma_kernel + conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; every contraction launched in the timed region)",
                          "flops_per_image": round(flops / (B * args.steps), 1),
-                         "event_ms": round(ev_ms, 3)},
+                         "event_ms": round(ev_ms, 3), "per_launch": per_launch},
         }
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, HW, 3, args.workload)
