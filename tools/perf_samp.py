@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from facet_amd import Engine
 from facet_amd._lib import FE_MODEL_SAMP, FE_MODEL_U2NETP
 from facet_amd.weights import synthetic_state_dict
-n = mb = 32
-eng = Engine(0, arena_bytes=24 << 30)
+n = mb = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+eng = Engine(0, arena_bytes=60 << 30)
 eng.set_microbatch(mb)
 x = np.random.default_rng(0).standard_normal((n, 3, 224, 224), dtype=np.float32)
 eng.load_weights(FE_MODEL_U2NETP, synthetic_state_dict("u2netp", 7))
