@@ -76,3 +76,32 @@ def test_samp_images_bgr_flag_and_clip_images(engine, all_loaded):
     feat, emb, aes = engine.clip_encode_images(imgs)
     rec, _ = engine.ensemble_score(imgs)
     assert np.allclose(rec[:, 21:], emb, atol=1e-6) and np.allclose(rec[:, 1], aes, rtol=1e-5, atol=1e-6)
+
+
+def test_crop_gathering_across_microbatches_is_order_preserving():
+    """CLIP and SAMP crops are gathered across micro-batches and run in larger chunks (ClipBatcher / SampBatcher in capi.hip): with
+    70 images, 16 per micro-batch, the towers run on a full chunk plus a remainder that was shifted inside the gather buffer.
+    Every image must get its own result: compare with one-image calls."""
+    from facet_amd import Engine
+    from facet_amd._lib import FE_MODEL_CLIP, FE_MODEL_AESTHETIC, FE_MODEL_SAMP, FE_MODEL_U2NETP
+    from facet_amd.weights import synthetic_state_dict, synthetic_images
+    e = Engine(0, arena_bytes=12 << 30)
+    e.load_weights(FE_MODEL_CLIP, synthetic_state_dict("clip", 5))
+    e.load_weights(FE_MODEL_AESTHETIC, synthetic_state_dict("aesthetic", 5))
+    e.load_weights(FE_MODEL_U2NETP, synthetic_state_dict("u2netp", 5))
+    e.load_weights(FE_MODEL_SAMP, synthetic_state_dict("samp_net", 5))
+    imgs = synthetic_images(11, 70, 96, 80)
+    e.set_microbatch(16)
+    feat, emb, aes = e.clip_encode_images(imgs)
+    pw, at, sd = e.samp_score_images(imgs)
+    rec, mask = e.ensemble_score(imgs)
+    assert mask == 6
+    for i in (0, 15, 16, 47, 62, 63, 64, 69):
+        f1, e1, a1 = e.clip_encode_images(imgs[i:i + 1])
+        p1, t1, s1 = e.samp_score_images(imgs[i:i + 1])
+        assert np.abs(feat[i] - f1[0]).max() <= 2e-5 * np.abs(f1).max() and abs(aes[i] - a1[0]) <= 2e-5 * max(1.0, abs(a1[0]))
+        assert np.abs(emb[i] - e1[0]).max() <= 2e-5
+        assert np.abs(pw[i] - p1[0]).max() <= 2e-5 * max(1.0, np.abs(p1).max()) and np.abs(sd[i] - s1[0]).max() <= 2e-5
+        assert np.abs(rec[i, 21:789] - e1[0]).max() <= 2e-5 and abs(rec[i, 1] - a1[0]) <= 2e-5 * max(1.0, abs(a1[0]))
+        assert np.abs(rec[i, 2:10] - p1[0]).max() <= 2e-5 * max(1.0, np.abs(p1).max())
+    e.close()
