@@ -1,0 +1,120 @@
+"""Generates tests/golden/host_golden.json by RUNNING THE REFERENCE'S OWN pure-Python functions in the build container
+(/root/reference is importable here; it does not exist on the GPU box, so the outputs are committed as a fixture).
+
+Covered (reference file:line): PyIQAScorer._normalize_score and ._preprocess_image (models/pyiqa_scorer.py:166-195, 137-164),
+SAMPNetScorer.score_batch's post-processing (models/samp_net.py:1016-1043, driven with a fake model that returns fixed
+tensors), CLIPTagger.get_tags_from_embedding / get_tags_with_scores / is_artwork (models/tagger.py:77-158, with hand-made text
+embeddings), FaceAnalyzer.calculate_ear / compute_avg_ear (analyzers/face.py:241-257; cv2 is absent, so a stub module named cv2
+is put in sys.modules for the import only - none of the pinned functions touches it).
+Nothing from the reference is copied: only inputs (seeded) and the outputs the reference code returned are stored.
+
+    python tests/golden/make_host_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from PIL import Image
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))        # import-time dependency of analyzers/face.py only
+
+out = {}
+
+# ---- PyIQAScorer ----------------------------------------------------------------------------------------------------
+from models.pyiqa_scorer import PyIQAScorer            # noqa: E402
+s = PyIQAScorer("topiq", device="cpu")
+raws = [-0.5, 0.0, 1e-4, 0.123456, 0.5, 0.731, 0.99995, 1.0, 1.7, float("nan")]
+out["normalize_score"] = {"raw": [None if r != r else r for r in raws], "out": []}
+for r in raws:
+    try:
+        v = s._normalize_score(r)
+        out["normalize_score"]["out"].append(None if v != v else float(v))
+    except Exception as e:       # record the failure mode too
+        out["normalize_score"]["out"].append("error:" + type(e).__name__)
+pre = []
+rng = np.random.default_rng(17)
+for (h, w, mode) in ((100, 120, "RGB"), (600, 2048, "RGB"), (1500, 900, "RGB"), (64, 64, "L"), (1024, 1024, "RGB"), (1025, 300, "RGBA")):
+    ch = {"RGB": 3, "L": 1, "RGBA": 4}[mode]
+    arr = rng.integers(0, 256, (h, w, ch) if ch > 1 else (h, w), dtype=np.uint8)
+    t = s._preprocess_image(Image.fromarray(arr, mode))
+    a = t.numpy() if hasattr(t, "numpy") else np.asarray(t)
+    pre.append({"h": h, "w": w, "mode": mode, "seed_order": len(pre), "shape": list(a.shape), "dtype": str(a.dtype),
+                "sha256": hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest(), "mean": float(a.mean()), "first": a.ravel()[:8].tolist()})
+out["preprocess_image"] = pre
+
+# ---- SAMPNetScorer post-processing ------------------------------------------------------------------------------------
+sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+tv = sys.modules["torchvision"]
+if not hasattr(tv, "transforms"):
+    tv.transforms = types.ModuleType("torchvision.transforms"); sys.modules["torchvision.transforms"] = tv.transforms
+    tv.models = types.ModuleType("torchvision.models"); sys.modules["torchvision.models"] = tv.models
+from models import samp_net as ref_samp                # noqa: E402
+g = torch.Generator().manual_seed(5)
+pw = torch.randn(6, 8, generator=g) * 2
+at = torch.sigmoid(torch.randn(6, 6, generator=g))
+sd = torch.softmax(torch.randn(6, 5, generator=g) * 1.5, dim=1)
+sd[0] = torch.tensor([0, 0, 0, 0, 1.0]); sd[1] = torch.tensor([1.0, 0, 0, 0, 0])        # the clamps
+sc = ref_samp.SAMPNetScorer.__new__(ref_samp.SAMPNetScorer)
+sc.preprocess = lambda img: img
+sc.saliency_detector = types.SimpleNamespace(detect=lambda x: None)
+sc.model = lambda x, sal: (pw, at, sd)
+dicts = sc.score_batch([torch.zeros(1, 3, 2, 2) for _ in range(6)])
+out["samp_postprocess"] = {"pattern_logits": pw.tolist(), "attributes": at.tolist(), "score_dist": sd.tolist(), "dicts": dicts}
+
+# ---- CLIPTagger ------------------------------------------------------------------------------------------------------
+from models.tagger import CLIPTagger                    # noqa: E402
+vocab = {"portrait": ["a person", "a face", "a portrait"], "landscape": ["a mountain", "a valley"], "painting": ["a painting"],
+         "night": ["the night sky", "stars"], "food": ["a meal"], "statue": ["a statue", "a sculpture"]}
+cfg = types.SimpleNamespace(get_tag_vocabulary=lambda: vocab, get_art_tags=lambda: {"painting", "statue"})
+tg = CLIPTagger(clip_model=None, device="cpu", config=cfg)
+names = [t for t, d in vocab.items() for _ in d]
+rng = np.random.default_rng(23)
+text = rng.standard_normal((len(names), 768)).astype(np.float32)
+text /= np.linalg.norm(text, axis=1, keepdims=True)
+tg.tag_names = names
+tg.text_embeddings = torch.from_numpy(text)
+cases = []
+for k in range(8):
+    mix = rng.uniform(0, 1, len(names)).astype(np.float32) * (rng.uniform(0, 1, len(names)) > 0.5)
+    emb = (mix @ text + 0.05 * rng.standard_normal(768)).astype(np.float32)
+    emb /= np.linalg.norm(emb)
+    b = emb.tobytes()
+    cases.append({"embedding_seed_order": k,
+                  "tags_default": tg.get_tags_from_embedding(b), "tags_t22_m5": tg.get_tags_from_embedding(b, threshold=0.22, max_tags=5),
+                  "tags_t05_m3": tg.get_tags_from_embedding(b, threshold=0.05, max_tags=3), "with_scores": tg.get_tags_with_scores(b, threshold=0.1),
+                  "is_artwork": bool(tg.is_artwork(b, threshold=0.2)), "embedding": emb.tolist()})
+out["tagger"] = {"vocabulary": vocab, "art_tags": ["painting", "statue"], "text_embeddings": text.tolist(), "cases": cases,
+                 "none_bytes": tg.get_tags_from_embedding(None)}
+
+# ---- FaceAnalyzer EAR ----------------------------------------------------------------------------------------------------
+from analyzers.face import FaceAnalyzer                 # noqa: E402
+ears = []
+for k in range(6):
+    lm = rng.uniform(0, 200, (106, 2)).astype(np.float32)
+    if k == 5:
+        lm[:] = 0
+    ears.append({"landmarks": lm.tolist(), "left": float(FaceAnalyzer.calculate_ear(lm, FaceAnalyzer.LEFT_EYE_INDICES)),
+                 "right": float(FaceAnalyzer.calculate_ear(lm, FaceAnalyzer.RIGHT_EYE_INDICES)), "avg": float(FaceAnalyzer.compute_avg_ear(lm))})
+out["ear"] = ears
+
+# ---- ModelManager sizing / pass packing (models/model_manager.py:631-648, 715-814; GPU-mode branches) ---------------------------
+from models.model_manager import ModelManager          # noqa: E402
+mm = ModelManager(types.SimpleNamespace(get_model_config=lambda: {"vram_profile": "16gb", "profiles": {"16gb": {"description": "x"}}}))
+hot = ["topiq", "clip", "samp_net", "insightface"]
+packs = []
+for models in (hot, ["clip", "topiq"], ["insightface", "samp_net", "topiq", "clip"], ["samp_net"], ["clip", "clip_aesthetic", "topiq", "samp_net", "insightface"]):
+    for vram in (3.0, 5.0, 7.0, 9.0, 11.0, 24.0, 288.0):
+        packs.append({"models": models, "vram": vram, "passes": mm.group_passes_by_vram(list(models), vram)})
+out["model_manager"] = {"packs": packs, "vram_gb": {m: mm.get_model_vram(m) for m in hot + ["clip_aesthetic"]},
+                        "profiles": {str(v): ModelManager.get_recommended_profile(v) for v in (0, 5.9, 6, 13.9, 14, 19.9, 20, 288)},
+                        "quality": {str(v): mm.select_quality_model(v) for v in (1.0, 1.9, 2.0, 3.5, 4.0, 288.0)}}
+
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_golden.json")
+json.dump(out, open(path, "w"))
+print("wrote", path, os.path.getsize(path), "bytes")
