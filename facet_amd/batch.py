@@ -1,0 +1,102 @@
+"""The batch step: what reference processing/batch_processor.py `_process_batch` (:169-360) and the multi-pass `_pass_*`
+functions (processing/multi_pass.py:481-644) sequence per image - one model after another, one image after another - as a
+handful of engine calls over a whole same-sized batch.
+
+    BatchScorer(engine, tagger=None, face_analyzer=None).process_batch(images_rgb) -> list[dict]
+
+Each dict carries, under the reference's own key names (batch_processor.py:298-354), every value that comes out of a model or
+a pixel scan: CLIP aesthetic + embedding blob, TOPIQ quality, SAMP-Net composition score / pattern, the face dict's fields,
+the seven technical-metric groups, tags, and the two cross terms the reference derives on the spot (face_ratio :244,
+isolation_bonus :264-269). What stays with the caller because it needs files, configuration policy or libraries outside the
+hot path: path / EXIF columns, phash (imagehash), rule-of-thirds placement and leading lines (CompositionAnalyzer),
+silhouette / category / aggregate (`detect_silhouette`, `Facet.calculate_aggregate_logic`) - `metrics_for_aggregate()` returns
+the exact `metrics` mapping that function expects (:272-296) with those caller-side fields left as given.
+
+Engine calls per batch: fe_ensemble_score (TOPIQ + CLIP + aesthetic + U2-Net-P + SAMP-Net), fe_image_stats (technical scans),
+fe_face_analyze + fe_roi_laplacian (through FaceAnalyzer.analyze_faces_batch), fe_tag_similarities (through CLIPTagger).
+"""
+import numpy as np
+
+from .image_stats import TechnicalAnalyzer
+from .samp_net import postprocess as samp_postprocess
+
+
+def tags_to_string(tags):
+    """utils/tags.py:8-20."""
+    return ','.join(tags) if tags else None
+
+
+class BatchScorer:
+    def __init__(self, engine, tagger=None, face_analyzer=None, tag_threshold=0.22, max_tags=5, mono_threshold=0.10,
+                 shadow_threshold=0.15, highlight_threshold=0.10):
+        self.engine, self.tagger, self.face_analyzer = engine, tagger, face_analyzer
+        self.tag_threshold, self.max_tags = tag_threshold, max_tags           # utils/tags.py:50-51 defaults
+        self.mono_threshold, self.shadow_threshold, self.highlight_threshold = mono_threshold, shadow_threshold, highlight_threshold
+
+    def process_batch(self, images_rgb):
+        """images_rgb: uint8 [n,h,w,3] (the PIL images of a batch as one array). Returns one dict per image."""
+        imgs = np.ascontiguousarray(images_rgb, dtype=np.uint8)
+        n, h, w, _ = imgs.shape
+        bgr = np.ascontiguousarray(imgs[..., ::-1])                          # img_cv of the reference
+        rec, mask = self.engine.ensemble_score(imgs)
+        tech = TechnicalAnalyzer.analyze_batch(self.engine, bgr, self.shadow_threshold, self.highlight_threshold, self.mono_threshold)
+        faces = self.face_analyzer.analyze_faces_batch(list(bgr)) if (self.face_analyzer is not None and self.face_analyzer.available) else None
+        tags = None
+        if self.tagger is not None and self.tagger.text_embeddings is not None and mask & 2:
+            tags = self.tagger.get_tags_batch(rec[:, 21:789], self.engine, self.tag_threshold, self.max_tags)
+        out = []
+        for i in range(n):
+            t = tech[i]
+            res = {'image_width': w, 'image_height': h}
+            if mask & 2:          # CLIP + aesthetic head: Facet.get_aesthetic_and_quality_batch (scorer.py:640-673)
+                aesthetic = max(0.0, min(10.0, (float(rec[i, 1]) + 1) * 5))
+                res.update({'aesthetic': round(aesthetic, 2), 'clip_embedding': rec[i, 21:789].astype(np.float32).tobytes(),
+                            'scoring_model': 'clip-mlp'})
+            res['quality_score'] = None
+            if mask & 1:          # TOPIQ pass (multi_pass.py:631-642): normalised score (pyiqa_scorer.py:166-195: clamp to [0,1], x10)
+                q = max(0.0, min(10.0, max(0.0, min(1.0, float(rec[i, 0]))) * 10.0))      # becomes aesthetic AND quality_score
+                if 'aesthetic' in res:
+                    res['clip_aesthetic'] = res['aesthetic']
+                res.update({'aesthetic': round(q, 2), 'quality_score': q, 'scoring_model': 'topiq'})
+            if mask & 4:          # SAMP-Net: get_composition_scores (scorer.py:675-700) overwrites comp_data['score']
+                sp = samp_postprocess(rec[i, 2:10], rec[i, 10:16], rec[i, 16:21])
+                res.update({'comp_score': round(sp['comp_score'], 2), 'composition_pattern': sp['pattern']})
+            res.update({
+                'tech_sharpness': round(t['sharpness']['normalized'], 2), 'raw_sharpness_variance': float(t['sharpness']['raw_variance']),
+                'color_score': round(t['color']['normalized'], 2), 'raw_color_entropy': float(t['color']['raw_entropy']),
+                'exposure_score': round(t['histogram']['exposure_score'], 2), 'histogram_data': t['histogram']['histogram_bytes'],
+                'histogram_spread': float(t['histogram']['spread']), 'mean_luminance': float(t['histogram']['mean_luminance']),
+                'histogram_bimodality': float(t['histogram']['bimodality']), 'shadow_clipped': t['histogram'].get('shadow_clipped', 0),
+                'highlight_clipped': t['histogram'].get('highlight_clipped', 0), 'is_monochrome': t['mono']['is_monochrome'],
+                'mean_saturation': t['mono']['mean_saturation'], 'dynamic_range_stops': t['dynamic_range']['dynamic_range_stops'],
+                'noise_sigma': t['noise']['noise_sigma'], 'contrast_score': t['contrast']['contrast_score'],
+            })
+            if faces is not None:
+                f = faces[i]
+                isolation, blink = 1.0, 0
+                if f['face_count'] > 0:      # batch_processor.py:264-269
+                    isolation = max(1.0, f['face_sharpness'] / (t['cache'].laplacian_variance + 1))
+                    blink = f.get('is_blink', 0)
+                res.update({'face_count': f['face_count'], 'face_quality': f['face_quality'], 'eye_sharpness': f['eye_sharpness'],
+                            'face_sharpness': f['face_sharpness'], 'face_ratio': f.get('face_area', 0) / (h * w),
+                            'raw_eye_sharpness': float(f.get('raw_eye_sharpness', 0)), 'is_group_portrait': f.get('is_group_portrait', 0),
+                            'face_confidence': f.get('max_face_confidence', 0), 'isolation_bonus': round(isolation, 2), 'is_blink': blink,
+                            'face_details': f.get('face_details', []), '_face_bbox': f.get('bbox'), '_isolation_bonus_raw': isolation})
+            res['tags'] = tags_to_string(tags[i]) if tags is not None else None
+            out.append(res)
+        return out
+
+    @staticmethod
+    def metrics_for_aggregate(res, exif=None, is_silhouette=0, comp_score=None):
+        """The `metrics` mapping `Facet.calculate_aggregate_logic` is called with (batch_processor.py:272-296), built from a
+        process_batch dict. comp_score: the caller's rule-based placement score when SAMP-Net is not loaded."""
+        exif = exif or {}
+        return {
+            'aesthetic': res.get('aesthetic'), 'face_count': res.get('face_count', 0), 'face_quality': res.get('face_quality', 0),
+            'eye_sharpness': res.get('eye_sharpness', 0), 'tech_sharpness': res['tech_sharpness'], 'color_score': res['color_score'],
+            'exposure_score': res['exposure_score'], 'face_ratio': res.get('face_ratio', 0),
+            'comp_score': res.get('comp_score', comp_score), 'isolation_bonus': res.get('_isolation_bonus_raw', 1.0),
+            'is_blink': res.get('is_blink', 0), 'shadow_clipped': res['shadow_clipped'], 'highlight_clipped': res['highlight_clipped'],
+            'is_silhouette': is_silhouette, 'histogram_spread': res['histogram_spread'], 'iso': exif.get('iso'), 'f_stop': exif.get('f_stop'),
+            'quality_score': res.get('quality_score'), 'scoring_model': res.get('scoring_model', 'clip-mlp'),
+        }

@@ -1,0 +1,62 @@
+"""The batch step (facet_amd/batch.py): the per-image dict assembled from whole-batch engine calls must equal
+what the per-model mirrors give image by image (the reference's own sequencing, processing/batch_processor.py:169-360)."""
+import types
+
+import numpy as np
+import pytest
+
+from facet_amd import synthetic_onnx as S
+from facet_amd._lib import FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_AESTHETIC, FE_MODEL_SAMP, FE_MODEL_U2NETP
+from facet_amd.batch import BatchScorer
+from facet_amd.face import FaceAnalyzer
+from facet_amd.image_stats import ImageCache, TechnicalAnalyzer
+from facet_amd.samp_net import postprocess
+from facet_amd.tagger import CLIPTagger
+from facet_amd.weights import synthetic_state_dict, synthetic_images
+
+pytestmark = pytest.mark.gpu
+
+
+def test_process_batch_equals_per_model_calls():
+    from facet_amd import Engine
+    e = Engine(0, arena_bytes=12 << 30)
+    for mid, name in ((FE_MODEL_TOPIQ, "topiq"), (FE_MODEL_CLIP, "clip"), (FE_MODEL_AESTHETIC, "aesthetic"), (FE_MODEL_U2NETP, "u2netp"), (FE_MODEL_SAMP, "samp_net")):
+        e.load_weights(mid, synthetic_state_dict(name, 4))
+    models = {"det": S.scrfd_like(seed=12, size=320)[0], "lmk": S.landmark_like(seed=13)[0], "rec": S.arcface_iresnet(layers=(1, 1, 1, 1), seed=14)[0]}
+    fa = FaceAnalyzer(min_confidence=0.55, min_face_size=10, engine=e, models=models)
+    fa.face_app.det_size, fa.face_app.max_candidates, fa.face_app.max_faces = (320, 320), 4096, 64
+    vocab = {"portrait": ["a person", "a face"], "landscape": ["a mountain"], "night": ["the night sky", "stars"]}
+    tg = CLIPTagger(config=types.SimpleNamespace(get_tag_vocabulary=lambda: vocab, get_art_tags=lambda: set()))
+    names = [t for t, d in vocab.items() for _ in d]
+    tg.set_text_embeddings(names, np.random.default_rng(1).standard_normal((len(names), 768)).astype(np.float32))
+    imgs = synthetic_images(6, 5, 224, 256)
+    bs = BatchScorer(e, tagger=tg, face_analyzer=fa, tag_threshold=-1.0, max_tags=2)
+    out = bs.process_batch(imgs)
+    assert len(out) == 5
+    topiq = e.topiq_score(imgs)
+    feat, emb, aes = e.clip_encode_images(imgs)
+    pw, at, sd = e.samp_score_images(imgs)
+    for i, r in enumerate(out):
+        q = max(0.0, min(1.0, float(topiq[i]))) * 10.0
+        assert r['quality_score'] == pytest.approx(q, rel=1e-5) and r['aesthetic'] == round(r['quality_score'], 2) and r['scoring_model'] == 'topiq'
+        assert r['clip_aesthetic'] == pytest.approx(round(max(0.0, min(10.0, (float(aes[i]) + 1) * 5)), 2), abs=0.011)
+        assert len(r['clip_embedding']) == 3072 and np.abs(np.frombuffer(r['clip_embedding'], np.float32) - emb[i]).max() < 2e-5
+        sp = postprocess(pw[i], at[i], sd[i])
+        assert r['composition_pattern'] == sp['pattern'] and r['comp_score'] == pytest.approx(sp['comp_score'], abs=0.011)
+        bgr = np.ascontiguousarray(imgs[i][..., ::-1])
+        c = ImageCache(bgr, engine=e)
+        assert r['raw_sharpness_variance'] == pytest.approx(c.laplacian_variance, rel=1e-12)
+        assert r['noise_sigma'] == TechnicalAnalyzer.get_noise_estimate(bgr, c)['noise_sigma']
+        assert r['contrast_score'] == TechnicalAnalyzer.get_contrast_score(bgr, c)['contrast_score']
+        assert r['histogram_data'] == TechnicalAnalyzer.get_histogram_data(bgr, 0.15, 0.10, c)['histogram_bytes']
+        f = fa.analyze_faces(bgr)
+        assert r['face_count'] == f['face_count'] and r['face_quality'] == f['face_quality']
+        assert r['face_sharpness'] == pytest.approx(f['face_sharpness'], rel=1e-9) and r['is_blink'] == (f['is_blink'] if f['face_count'] else 0)
+        if f['face_count']:
+            assert r['isolation_bonus'] == round(max(1.0, f['face_sharpness'] / (c.laplacian_variance + 1)), 2)
+            assert r['face_ratio'] == pytest.approx(f['face_area'] / (224 * 256), rel=1e-12)
+        assert r['tags'] is not None and len(r['tags'].split(',')) == 2
+        m = BatchScorer.metrics_for_aggregate(r, exif={'iso': 400, 'f_stop': 2.8})
+        assert m['aesthetic'] == r['aesthetic'] and m['iso'] == 400 and m['comp_score'] == r['comp_score'] and m['quality_score'] == r['quality_score']
+    fa.face_app.unload()
+    e.close()
