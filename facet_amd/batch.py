@@ -8,8 +8,8 @@ Each dict carries, under the reference's own key names (batch_processor.py:298-3
 a pixel scan: CLIP aesthetic + embedding blob, TOPIQ quality, SAMP-Net composition score / pattern, the face dict's fields,
 the seven technical-metric groups, tags, and the two cross terms the reference derives on the spot (face_ratio :244,
 isolation_bonus :264-269). What stays with the caller because it needs files, configuration policy or libraries outside the
-hot path: path / EXIF columns, phash (imagehash), rule-of-thirds placement and leading lines (CompositionAnalyzer),
-silhouette / category / aggregate (`detect_silhouette`, `Facet.calculate_aggregate_logic`) - `metrics_for_aggregate()` returns
+hot path: path / EXIF columns, phash (imagehash), leading lines (CompositionAnalyzer.detect_leading_lines),
+category / aggregate (`Facet.calculate_aggregate_logic`, configuration policy) - `metrics_for_aggregate()` returns
 the exact `metrics` mapping that function expects (:272-296) with those caller-side fields left as given.
 
 Engine calls per batch: fe_ensemble_score (TOPIQ + CLIP + aesthetic + U2-Net-P + SAMP-Net), fe_image_stats (technical scans),
@@ -26,10 +26,36 @@ def tags_to_string(tags):
     return ','.join(tags) if tags else None
 
 
+def placement_data(bbox, img_w, img_h, power_weight=2.0, line_weight=1.0):
+    """CompositionAnalyzer.get_placement_data(bbox, w, h, config) as `_process_batch` calls it (batch_processor.py:245-247, without
+    img_cv): rule-of-thirds power points / lines vs centred composition; analyzers/composition.py:111-187. The two weights are
+    config.get_composition_weights()'s power_point_weight / line_weight."""
+    if bbox is None:
+        return {'score': 7.0, 'power_point_score': 5.0, 'line_score': 5.0, 'center_score': 7.0}
+    cx = (bbox[0] + bbox[2]) / 2 / img_w
+    cy = (bbox[1] + bbox[3]) / 2 / img_h
+    thirds = [1 / 3, 2 / 3]
+    nearest_pp = min(np.sqrt((cx - px) ** 2 + (cy - py) ** 2) for px in thirds for py in thirds)
+    pp = max(0, 10 - nearest_pp * 25)
+    line = max(0, 10 - (min(abs(cx - t) for t in thirds) + min(abs(cy - t) for t in thirds)) * 15)
+    centre = max(0, 10 - (abs(cx - 0.5) + abs(cy - 0.5)) * 10)
+    best = max((pp * power_weight + line * line_weight) / (power_weight + line_weight), centre)
+    return {'score': round(best, 2), 'power_point_score': round(pp, 2), 'line_score': round(line, 2), 'center_score': round(centre, 2)}
+
+
+def detect_silhouette(histogram_silhouette, tags, face_count):
+    """utils/detection.py:8-29: (histogram silhouette or a 'silhouette' tag) and a human (a face, or a portrait / group tag).
+    `tags` is the comma-joined tag string (substring tests, as in the reference)."""
+    tagged = ('silhouette' in tags) if tags else False
+    human = face_count > 0 or (any(t in tags for t in ('portrait', 'group')) if tags else False)
+    return 1 if ((histogram_silhouette or tagged) and human) else 0
+
+
 class BatchScorer:
     def __init__(self, engine, tagger=None, face_analyzer=None, tag_threshold=0.22, max_tags=5, mono_threshold=0.10,
-                 shadow_threshold=0.15, highlight_threshold=0.10):
+                 shadow_threshold=0.15, highlight_threshold=0.10, power_weight=2.0, line_weight=1.0):
         self.engine, self.tagger, self.face_analyzer = engine, tagger, face_analyzer
+        self.power_weight, self.line_weight = power_weight, line_weight
         self.tag_threshold, self.max_tags = tag_threshold, max_tags           # utils/tags.py:50-51 defaults
         self.mono_threshold, self.shadow_threshold, self.highlight_threshold = mono_threshold, shadow_threshold, highlight_threshold
 
@@ -71,6 +97,7 @@ class BatchScorer:
                 'mean_saturation': t['mono']['mean_saturation'], 'dynamic_range_stops': t['dynamic_range']['dynamic_range_stops'],
                 'noise_sigma': t['noise']['noise_sigma'], 'contrast_score': t['contrast']['contrast_score'],
             })
+            res['tags'] = tags_to_string(tags[i]) if tags is not None else None
             if faces is not None:
                 f = faces[i]
                 isolation, blink = 1.0, 0
@@ -82,12 +109,16 @@ class BatchScorer:
                             'raw_eye_sharpness': float(f.get('raw_eye_sharpness', 0)), 'is_group_portrait': f.get('is_group_portrait', 0),
                             'face_confidence': f.get('max_face_confidence', 0), 'isolation_bonus': round(isolation, 2), 'is_blink': blink,
                             'face_details': f.get('face_details', []), '_face_bbox': f.get('bbox'), '_isolation_bonus_raw': isolation})
-            res['tags'] = tags_to_string(tags[i]) if tags is not None else None
+            # rule-based placement of the (union) face box, then SAMP-Net's score on top when it ran (scorer.py:675-690)
+            comp = placement_data(res.get('_face_bbox'), w, h, self.power_weight, self.line_weight)
+            res['power_point_score'] = float(comp['power_point_score'])
+            res.setdefault('comp_score', round(comp['score'], 2))
+            res['is_silhouette'] = detect_silhouette(t['histogram'].get('is_silhouette', 0), res.get('tags'), res.get('face_count', 0))
             out.append(res)
         return out
 
     @staticmethod
-    def metrics_for_aggregate(res, exif=None, is_silhouette=0, comp_score=None):
+    def metrics_for_aggregate(res, exif=None, is_silhouette=None, comp_score=None):
         """The `metrics` mapping `Facet.calculate_aggregate_logic` is called with (batch_processor.py:272-296), built from a
         process_batch dict. comp_score: the caller's rule-based placement score when SAMP-Net is not loaded."""
         exif = exif or {}
@@ -97,6 +128,6 @@ class BatchScorer:
             'exposure_score': res['exposure_score'], 'face_ratio': res.get('face_ratio', 0),
             'comp_score': res.get('comp_score', comp_score), 'isolation_bonus': res.get('_isolation_bonus_raw', 1.0),
             'is_blink': res.get('is_blink', 0), 'shadow_clipped': res['shadow_clipped'], 'highlight_clipped': res['highlight_clipped'],
-            'is_silhouette': is_silhouette, 'histogram_spread': res['histogram_spread'], 'iso': exif.get('iso'), 'f_stop': exif.get('f_stop'),
+            'is_silhouette': res.get('is_silhouette', 0) if is_silhouette is None else is_silhouette, 'histogram_spread': res['histogram_spread'], 'iso': exif.get('iso'), 'f_stop': exif.get('f_stop'),
             'quality_score': res.get('quality_score'), 'scoring_model': res.get('scoring_model', 'clip-mlp'),
         }

@@ -115,6 +115,26 @@ out["model_manager"] = {"packs": packs, "vram_gb": {m: mm.get_model_vram(m) for 
                         "profiles": {str(v): ModelManager.get_recommended_profile(v) for v in (0, 5.9, 6, 13.9, 14, 19.9, 20, 288)},
                         "quality": {str(v): mm.select_quality_model(v) for v in (1.0, 1.9, 2.0, 3.5, 4.0, 288.0)}}
 
+# ---- CompositionAnalyzer.get_placement_data (analyzers/composition.py:111-187; pure arithmetic on the face box) ---------------
+from analyzers.composition import CompositionAnalyzer  # noqa: E402
+plc = []
+for k in range(12):
+    w_, h_ = int(rng.integers(200, 2000)), int(rng.integers(200, 2000))
+    x1, y1 = rng.uniform(0, w_ * 0.8), rng.uniform(0, h_ * 0.8)
+    bbox = [int(x1), int(y1), int(x1 + rng.uniform(5, w_ * 0.2)), int(y1 + rng.uniform(5, h_ * 0.2))]
+    cfg_w = None if k % 3 else types.SimpleNamespace(get_composition_weights=lambda: {"power_point_weight": 3.0, "line_weight": 0.5})
+    plc.append({"bbox": bbox, "w": w_, "h": h_, "weights": [3.0, 0.5] if cfg_w else [2.0, 1.0],
+                "out": CompositionAnalyzer.get_placement_data(np.array(bbox), w_, h_, cfg_w)})
+plc.append({"bbox": None, "w": 640, "h": 480, "weights": [2.0, 1.0], "out": CompositionAnalyzer.get_placement_data(None, 640, 480, None)})
+out["placement"] = plc
+from utils.detection import detect_silhouette          # noqa: E402
+sil = []
+for hs in (0, 1):
+    for tags in (None, "", "silhouette", "portrait,night", "silhouette,group", "landscape", "silhouette,landscape"):
+        for fc in (0, 2):
+            sil.append({"hist": hs, "tags": tags, "faces": fc, "out": detect_silhouette({"is_silhouette": hs}, tags, fc)})
+out["silhouette"] = sil
+
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_golden.json")
 json.dump(out, open(path, "w"))
 print("wrote", path, os.path.getsize(path), "bytes")

@@ -101,3 +101,16 @@ def test_model_manager_sizing_matches_reference():
         assert mm.select_quality_model(float(v)) == model, v
     for c in g["packs"]:
         assert mm.group_passes_by_vram(list(c["models"]), c["vram"]) == c["passes"], (c["models"], c["vram"])
+
+
+def test_placement_data_matches_reference():
+    from facet_amd.batch import placement_data
+    for c in G["placement"]:
+        got = placement_data(None if c["bbox"] is None else np.array(c["bbox"]), c["w"], c["h"], *c["weights"])
+        assert got == c["out"], (c["bbox"], got, c["out"])
+
+
+def test_detect_silhouette_matches_reference():
+    from facet_amd.batch import detect_silhouette
+    for c in G["silhouette"]:
+        assert detect_silhouette(c["hist"], c["tags"], c["faces"]) == c["out"], c
