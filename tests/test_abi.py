@@ -49,3 +49,22 @@ def test_product_package_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports oracle"
+
+
+def test_plain_c_program_links_and_runs(tmp_path):
+    """examples/score_topiq.c: a C99 program compiled against include/facet_engine.h and linked to the in-tree library. On a box
+    without a GPU it must still start, parse a model with the host-only entry point and report the missing device cleanly."""
+    import shutil
+    import subprocess
+    from facet_amd import synthetic_onnx as S
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    exe = str(tmp_path / "score_topiq")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "score_topiq.c"), "-o", exe,
+                    "-L" + os.path.join(root, "facet_amd"), "-lfacet_engine", "-Wl,-rpath," + os.path.join(root, "facet_amd")], check=True)
+    model = tmp_path / "m.onnx"
+    model.write_bytes(S.landmark_like(seed=1)[0])
+    out = subprocess.run([exe, str(model)], check=True, capture_output=True, text=True, timeout=120).stdout
+    assert "facet_amd" in out and "73 nodes" in out and "input [1,3,192,192]" in out
+    assert ("no engine context" in out) or ("fe_topiq_score -> " in out)      # CPU box / GPU box without weights
