@@ -55,6 +55,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_double), _f32p]),
     "fe_flops_reset": (C.c_int, [C.c_void_p]),
     "fe_flops_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "fe_flops_get_executed": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "fe_weights_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "fe_weights_set": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, _f32p, _i64p, C.c_int]),
     "fe_weights_commit": (C.c_int, [C.c_void_p, C.c_int]),
@@ -218,6 +219,11 @@ class Engine:
             self._ck(self.lib.fe_profile_get(self.h, i, buf, 160, C.byref(fl), C.byref(by), C.byref(ms)))
             out.append({"name": buf.value.decode(), "flops": fl.value, "bytes": by.value, "ms": ms.value})
         return out
+
+    def flops_executed(self):
+        f = C.c_double()
+        self._ck(self.lib.fe_flops_get_executed(self.h, C.byref(f)))
+        return f.value
 
     def flops_reset(self):
         self._ck(self.lib.fe_flops_reset(self.h))

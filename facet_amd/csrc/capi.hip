@@ -236,6 +236,13 @@ int fe_profile_get(fe_ctx* ctx, int i, char* name, int name_cap, double* flops, 
 int fe_flops_reset(fe_ctx* ctx) {
   FE_API_BEGIN(ctx)
   ctx->c.flops_accum = 0.0;
+  ctx->c.flops_saved = 0.0;
+  FE_API_END(ctx)
+}
+int fe_flops_get_executed(fe_ctx* ctx, double* flops) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(flops, "bad arguments");
+  *flops = ctx->c.flops_accum - ctx->c.flops_saved;
   FE_API_END(ctx)
 }
 int fe_flops_get(fe_ctx* ctx, double* flops) {

@@ -124,6 +124,7 @@ struct Ctx {
   bool profile = false;
   std::vector<OpTiming> timings;
   double flops_accum = 0.0;
+  double flops_saved = 0.0;   // algorithmic FLOPs NOT executed because a layer ran as Winograd (executed = flops_accum - flops_saved)
   int force_variant = 0;   // developer hook: forwarded to ConvParams.variant
 
   std::map<std::tuple<int, int, int>, ResizeCoeffsDev> resize_cache;  // (in, out, filter) -> device tables

@@ -88,6 +88,26 @@ ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>
       c.wstem = dw.upload(st);
     }
   }
+  if (c.KH == 3 && c.KW == 3 && c.Cin == c.CinPad && c.Cin % 32 == 0 && c.Cin >= 256 && c.Cout % 4 == 0) {
+    // Winograd F(2x2,3x3) weights U = G g G^T per (cout, cin), in double. Layout [16][Cout][Cin]; the epilogue scale / shift /
+    // activation are applied by the output transform (ConvW.scale may be attached after packing).
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    std::vector<float> U((size_t)16 * c.Cout * c.Cin);
+    for (int co = 0; co < c.Cout; ++co) {
+      for (int ci = 0; ci < c.Cin; ++ci) {
+        const float* g = &w.data[((size_t)co * c.Cin + ci) * 9];
+        double tmp[4][3];
+        for (int a = 0; a < 4; ++a)
+          for (int q = 0; q < 3; ++q) tmp[a][q] = Gm[a][0] * g[q] + Gm[a][1] * g[3 + q] + Gm[a][2] * g[6 + q];
+        for (int a = 0; a < 4; ++a)
+          for (int b = 0; b < 4; ++b) {
+            const double u = tmp[a][0] * Gm[b][0] + tmp[a][1] * Gm[b][1] + tmp[a][2] * Gm[b][2];
+            U[((size_t)(4 * a + b) * c.Cout + co) * c.Cin + ci] = (float)u;
+          }
+      }
+    }
+    c.wino = dw.upload(U);
+  }
   if (scale) c.scale = dw.upload(*scale);
   if (shift) c.shift = dw.upload(*shift);
   return c;
@@ -195,6 +215,47 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
     c.arena.rewind(mark);
     c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout);
     return;
+  }
+  // Winograd F(2x2,3x3) for the deep 3x3 stride-1 layers: input transform -> 16 batched GEMMs (one launch) -> output transform
+  static const bool no_wino = getenv("FE_NO_WINO") != nullptr;
+  if (w.wino && !no_wino && p.variant == 0 && o.sh == 1 && o.sw == 1 && o.ph == 1 && o.pw == 1 && o.dh == 1 && o.dw == 1 && !o.res &&
+      !o.gate && (o.act == ACT_NONE || o.act == ACT_RELU) && y.h == x.h && y.w == x.w && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0 &&
+      x.ld % 4 == 0 && y.ld % 4 == 0) {
+    const int th = (x.h + 1) / 2, tw = (x.w + 1) / 2;
+    const size_t tiles = (size_t)x.n * th * tw;
+    if (tiles < (1u << 30) / 16) {
+      const size_t mark = c.arena.mark();
+      float* V = (float*)c.arena.alloc((size_t)16 * tiles * w.Cin * sizeof(float));
+      float* Mb = (float*)c.arena.alloc((size_t)16 * tiles * w.Cout * sizeof(float));
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (c.profile) {
+        FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
+        FE_HIP(hipEventRecord(e0, c.stream));
+      }
+      launch_wino_input(x, th, tw, V, c.stream);
+      ConvParams g{};
+      g.x = V; g.ldx = w.Cin; g.w = w.wino; g.ldw = w.Cin; g.y = Mb; g.ldy = w.Cout;
+      g.M = (int)tiles; g.K = w.Cin; g.Cout = w.Cout;
+      g.N = 1; g.H = 1; g.W = g.M; g.Ho = 1; g.Wo = g.M; g.KH = g.KW = 1; g.sh = g.sw = g.dh = g.dw = 1;
+      g.Kp = w.Cin; g.Cin = w.Cin;
+      g.batch = 16; g.nb1 = 1; g.xs2 = (long long)tiles * w.Cin; g.ws2 = (long long)w.Cout * w.Cin; g.ys2 = (long long)tiles * w.Cout;
+      launch_conv(g, c.stream);
+      launch_wino_output(Mb, y, th, tw, w.scale, w.shift, o.act == ACT_RELU, c.stream);
+      if (c.profile) {   // one record for the three launches, with the direct convolution's FLOPs
+        FE_HIP(hipEventRecord(e1, c.stream));
+        FE_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        FE_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        char nm[128];
+        snprintf(nm, sizeof nm, "wino3x3 M=%d K=%d N=%d", p.M, p.K, p.Cout);
+        c.timings.push_back({nm, 2.0 * p.M * (double)(9 * w.Cin) * p.Cout, 0.0, ms});
+      }
+      c.arena.rewind(mark);
+      c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout);   // algorithmic = the direct convolution's
+      c.flops_saved += 2.0 * p.M * (double)(9 * w.Cin) * p.Cout - 2.0 * 16.0 * (double)tiles * w.Cin * w.Cout;
+      return;
+    }
   }
   // dedicated stem kernel (patch + weights resident in LDS) for 7x7/2 and 3x3/1|2 first layers; falls back otherwise
   static const bool no_stem = getenv("FE_NO_STEM") != nullptr;

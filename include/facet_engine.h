@@ -74,6 +74,9 @@ int fe_profile_get(fe_ctx* ctx, int i, char* name, int name_cap, double* flops, 
 /* algorithmic FLOPs issued since the last fe_flops_reset (2*MAC of every contraction launched) */
 int fe_flops_reset(fe_ctx* ctx);
 int fe_flops_get(fe_ctx* ctx, double* flops);
+/* Same counter minus the multiply-adds saved where a layer ran as Winograd F(2x2,3x3) (16 instead of 36 per 2x2 outputs):
+ * the FLOPs the matrix cores actually executed. fe_flops_get stays the algorithmic (direct-convolution) count. */
+int fe_flops_get_executed(fe_ctx* ctx, double* flops);
 
 /* ---- weights: replaces state_dict loading inside pyiqa.create_metric / open_clip.create_model /
  *      SAMPNet.load_state_dict (models/pyiqa_scorer.py:108, model_manager.py:140, samp_net.py:895).

@@ -157,3 +157,19 @@ def test_stem3x3_kernel_matches_torch(engine, cout, stride, hw):
     got = engine.conv2d(x, w, shift=sh, stride=stride, pad=1, act="relu")
     ref = F.relu(F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(sh), stride=stride, padding=1)).numpy()
     assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("cin,cout,hw,act", [(256, 256, (14, 14), "relu"), (512, 384, (13, 17), None), (256, 64, (1, 5), "relu"), (320, 256, (32, 32), "relu")])
+def test_winograd_path_matches_torch(engine, cin, cout, hw, act):
+    """3x3 / stride 1 / pad 1 with Cin >= 256 runs as Winograd F(2x2,3x3): transforms + 16 batched GEMMs (odd sizes: partial tiles)."""
+    rng = np.random.default_rng(cin + hw[0])
+    x = rng.standard_normal((2, cin, hw[0], hw[1])).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) * (1.0 / np.sqrt(9 * cin))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    got = engine.conv2d(x, w, scale=sc, shift=sh, stride=1, pad=1, act=act)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1) * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1)
+    if act == "relu":
+        ref = F.relu(ref)
+    ref = ref.numpy()
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
