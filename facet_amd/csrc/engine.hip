@@ -88,25 +88,31 @@ ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>
       c.wstem = dw.upload(st);
     }
   }
-  if (c.KH == 3 && c.KW == 3 && c.Cin == c.CinPad && c.Cin % 32 == 0 && c.Cin >= 256 && c.Cout % 4 == 0) {
-    // Winograd F(2x2,3x3) weights U = G g G^T per (cout, cin), in double. Layout [16][Cout][Cin]; the epilogue scale / shift /
-    // activation are applied by the output transform (ConvW.scale may be attached after packing).
-    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    std::vector<float> U((size_t)16 * c.Cout * c.Cin);
-    for (int co = 0; co < c.Cout; ++co) {
+  static const int wino_min_cin = getenv("FE_WINO_MIN_CIN") ? atoi(getenv("FE_WINO_MIN_CIN")) : 128;   // tuning hooks; defaults measured best (profiles/r01_README.md)
+  static const int wino_form = getenv("FE_WINO_FORM") ? atoi(getenv("FE_WINO_FORM")) : 4;
+  if ((wino_form == 2 || wino_form == 4) && c.KH == 3 && c.KW == 3 && c.Cin == c.CinPad && c.Cin % 32 == 0 && c.Cin >= wino_min_cin && c.Cout % 4 == 0) {
+    // Winograd weights U = G g G^T per (cout, cin), in double. Layout [planes][Cout][Cin]; the epilogue scale / shift / activation
+    // are applied by the output transform (ConvW.scale may be attached after packing).
+    static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    static const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int R = wino_form == 2 ? 4 : 6;
+    auto Gm = [&](int a, int q) { return wino_form == 2 ? G2[a][q] : G4[a][q]; };
+    std::vector<float> U((size_t)R * R * c.Cout * c.Cin);
+    for (int co = 0; co < c.Cout; ++co)
       for (int ci = 0; ci < c.Cin; ++ci) {
         const float* g = &w.data[((size_t)co * c.Cin + ci) * 9];
-        double tmp[4][3];
-        for (int a = 0; a < 4; ++a)
-          for (int q = 0; q < 3; ++q) tmp[a][q] = Gm[a][0] * g[q] + Gm[a][1] * g[3 + q] + Gm[a][2] * g[6 + q];
-        for (int a = 0; a < 4; ++a)
-          for (int b = 0; b < 4; ++b) {
-            const double u = tmp[a][0] * Gm[b][0] + tmp[a][1] * Gm[b][1] + tmp[a][2] * Gm[b][2];
-            U[((size_t)(4 * a + b) * c.Cout + co) * c.Cin + ci] = (float)u;
+        double tmp[6][3];
+        for (int a = 0; a < R; ++a)
+          for (int q = 0; q < 3; ++q) tmp[a][q] = Gm(a, 0) * g[q] + Gm(a, 1) * g[3 + q] + Gm(a, 2) * g[6 + q];
+        for (int a = 0; a < R; ++a)
+          for (int b = 0; b < R; ++b) {
+            const double u = tmp[a][0] * Gm(b, 0) + tmp[a][1] * Gm(b, 1) + tmp[a][2] * Gm(b, 2);
+            U[((size_t)(R * a + b) * c.Cout + co) * c.Cin + ci] = (float)u;
           }
       }
-    }
     c.wino = dw.upload(U);
+    c.wino_m = wino_form;
   }
   if (scale) c.scale = dw.upload(*scale);
   if (shift) c.shift = dw.upload(*shift);
@@ -216,31 +222,35 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
     c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout);
     return;
   }
-  // Winograd F(2x2,3x3) for the deep 3x3 stride-1 layers: input transform -> 16 batched GEMMs (one launch) -> output transform
+  // Winograd F(4x4,3x3) (or F(2x2,3x3)) for the deep 3x3 stride-1 layers: input transform -> 36 (16) batched GEMMs in ONE launch
+  // -> output transform with the epilogue
   static const bool no_wino = getenv("FE_NO_WINO") != nullptr;
   if (w.wino && !no_wino && p.variant == 0 && o.sh == 1 && o.sw == 1 && o.ph == 1 && o.pw == 1 && o.dh == 1 && o.dw == 1 && !o.res &&
       !o.gate && (o.act == ACT_NONE || o.act == ACT_RELU) && y.h == x.h && y.w == x.w && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0 &&
       x.ld % 4 == 0 && y.ld % 4 == 0) {
-    const int th = (x.h + 1) / 2, tw = (x.w + 1) / 2;
+    const int ts = w.wino_m, planes = (ts + 2) * (ts + 2);       // output tile side 2 or 4; 16 or 36 planes
+    const int th = (x.h + ts - 1) / ts, tw = (x.w + ts - 1) / ts;
     const size_t tiles = (size_t)x.n * th * tw;
-    if (tiles < (1u << 30) / 16) {
+    if (tiles < (1u << 30) / 36) {
       const size_t mark = c.arena.mark();
-      float* V = (float*)c.arena.alloc((size_t)16 * tiles * w.Cin * sizeof(float));
-      float* Mb = (float*)c.arena.alloc((size_t)16 * tiles * w.Cout * sizeof(float));
+      float* V = (float*)c.arena.alloc((size_t)planes * tiles * w.Cin * sizeof(float));
+      float* Mb = (float*)c.arena.alloc((size_t)planes * tiles * w.Cout * sizeof(float));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (c.profile) {
         FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
         FE_HIP(hipEventRecord(e0, c.stream));
       }
-      launch_wino_input(x, th, tw, V, c.stream);
+      if (ts == 2) launch_wino_input(x, th, tw, V, c.stream);
+      else launch_wino4_input(x, th, tw, V, c.stream);
       ConvParams g{};
       g.x = V; g.ldx = w.Cin; g.w = w.wino; g.ldw = w.Cin; g.y = Mb; g.ldy = w.Cout;
       g.M = (int)tiles; g.K = w.Cin; g.Cout = w.Cout;
       g.N = 1; g.H = 1; g.W = g.M; g.Ho = 1; g.Wo = g.M; g.KH = g.KW = 1; g.sh = g.sw = g.dh = g.dw = 1;
       g.Kp = w.Cin; g.Cin = w.Cin;
-      g.batch = 16; g.nb1 = 1; g.xs2 = (long long)tiles * w.Cin; g.ws2 = (long long)w.Cout * w.Cin; g.ys2 = (long long)tiles * w.Cout;
+      g.batch = planes; g.nb1 = 1; g.xs2 = (long long)tiles * w.Cin; g.ws2 = (long long)w.Cout * w.Cin; g.ys2 = (long long)tiles * w.Cout;
       launch_conv(g, c.stream);
-      launch_wino_output(Mb, y, th, tw, w.scale, w.shift, o.act == ACT_RELU, c.stream);
+      if (ts == 2) launch_wino_output(Mb, y, th, tw, w.scale, w.shift, o.act == ACT_RELU, c.stream);
+      else launch_wino4_output(Mb, y, th, tw, w.scale, w.shift, o.act == ACT_RELU, c.stream);
       if (c.profile) {   // one record for the three launches, with the direct convolution's FLOPs
         FE_HIP(hipEventRecord(e1, c.stream));
         FE_HIP(hipEventSynchronize(e1));
@@ -253,7 +263,7 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
       }
       c.arena.rewind(mark);
       c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout);   // algorithmic = the direct convolution's
-      c.flops_saved += 2.0 * p.M * (double)(9 * w.Cin) * p.Cout - 2.0 * 16.0 * (double)tiles * w.Cin * w.Cout;
+      c.flops_saved += 2.0 * p.M * (double)(9 * w.Cin) * p.Cout - 2.0 * (double)planes * (double)tiles * w.Cin * w.Cout;
       return;
     }
   }

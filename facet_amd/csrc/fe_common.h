@@ -133,6 +133,7 @@ struct ConvW {
   int CoutAlg = 0;         // logical output channels when Cout carries zero padding (FLOP accounting only; 0 => Cout)
   // Cout <= 2 spatial kernels also carry a tap-decomposed form: rows (tap, co) of a 1x1 conv [KH*KW*Cout][KpT]
   float* wtap = nullptr;
+  int wino_m = 0;          // 2 or 4: which Winograd form `wino` holds (F(2x2,3x3): 16 planes, F(4x4,3x3): 36 planes)
   float* wino = nullptr;   // 3x3 convs with Cin >= 256 also carry Winograd F(2x2,3x3) weights U[16][Cout][Cin]
   float* wstem = nullptr;  // 7x7 or 3x3, Cin <= 3, Cout 32|64 stems also carry the [taps][Cout][4] layout of kernels_stem.hip
   int KpT = 0;
@@ -152,6 +153,8 @@ void launch_conv(const ConvParams& p, hipStream_t s);
 // Winograd transforms (kernels_winograd.hip): V / M are [16][tiles][C] planes
 void launch_wino_input(const Tensor& x, int th, int tw, float* V, hipStream_t s);
 void launch_wino_output(const float* Mb, const Tensor& y, int th, int tw, const float* scale, const float* shift, int relu, hipStream_t s);
+void launch_wino4_input(const Tensor& x, int th, int tw, float* V, hipStream_t s);     // F(4x4,3x3): [36][tiles][C] planes
+void launch_wino4_output(const float* Mb, const Tensor& y, int th, int tw, const float* scale, const float* shift, int relu, hipStream_t s);
 bool launch_stem(const float* x, int ldx, int N, int H, int W, const float* wstem, const float* scale, const float* shift, const float* slope,
                  int Cout, int k, int stride, int act, float* y, int ldy, int Ho, int Wo, hipStream_t s);   // kernels_stem.hip; false = shape not handled
 void launch_conv_narrow(const ConvParams& p, hipStream_t s);            // Cout <= 4, no MFMA (kernels_misc.hip)

@@ -116,4 +116,107 @@ void launch_wino_output(const float* Mb, const Tensor& y, int th, int tw, const 
   FE_HIP(hipGetLastError());
 }
 
+// ---- F(4x4, 3x3): 36 multiplies per 4x4 outputs (4x fewer MACs than direct), 6x6 input tiles with stride 4 ------------------------
+//   B^T rows: [4 0 -5 0 1 0] [0 -4 -4 1 1 0] [0 4 -4 -1 1 0] [0 -2 -1 2 1 0] [0 2 -1 -2 1 0] [0 4 0 -5 0 1]
+//   A^T rows: [1 1 1 1 1 0] [0 1 -1 2 -2 0] [0 1 1 4 4 0] [0 1 -1 8 -8 1]            (Lavin & Gray 2015)
+// One thread = one tile x ONE channel (36 live values); consecutive lanes take consecutive channels, so every access of a
+// wavefront is a contiguous 256-B run.
+__device__ __forceinline__ void bt6(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5, float* o) {
+  o[0] = 4.f * d0 - 5.f * d2 + d4;
+  o[1] = -4.f * d1 - 4.f * d2 + d3 + d4;
+  o[2] = 4.f * d1 - 4.f * d2 - d3 + d4;
+  o[3] = -2.f * d1 - d2 + 2.f * d3 + d4;
+  o[4] = 2.f * d1 - d2 - 2.f * d3 + d4;
+  o[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int ldx, int N, int H, int W, int C, int th, int tw,
+                                                          float* __restrict__ V, size_t plane) {
+  const size_t total = (size_t)N * th * tw * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const int img = (int)(t / ((size_t)tw * th));
+    float tm[6][6];   // B^T d, built column by column
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int ix = 4 * tx - 1 + q;
+      float col[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int iy = 4 * ty - 1 + r;
+        col[r] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? x[(((size_t)img * H + iy) * W + ix) * ldx + c] : 0.f;
+      }
+      float o[6];
+      bt6(col[0], col[1], col[2], col[3], col[4], col[5], o);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) tm[r][q] = o[r];
+    }
+    float* dst = V + t * (size_t)C + c;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float o[6];
+      bt6(tm[r][0], tm[r][1], tm[r][2], tm[r][3], tm[r][4], tm[r][5], o);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dst[(size_t)(6 * r + q) * plane] = o[q];
+    }
+  }
+}
+__device__ __forceinline__ void at4(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5, float* o) {
+  o[0] = m0 + m1 + m2 + m3 + m4;
+  o[1] = m1 - m2 + 2.f * m3 - 2.f * m4;
+  o[2] = m1 + m2 + 4.f * m3 + 4.f * m4;
+  o[3] = m1 - m2 + 8.f * m3 - 8.f * m4 + m5;
+}
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mb, size_t plane, int N, int H, int W, int C, int th, int tw,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                           float* __restrict__ y, int ldy) {
+  const size_t total = (size_t)N * th * tw * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const int img = (int)(t / ((size_t)tw * th));
+    const float* src = Mb + t * (size_t)C + c;
+    float s[4][6];   // A^T m, column by column
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      float o[4];
+      at4(src[(size_t)(0 * 6 + q) * plane], src[(size_t)(1 * 6 + q) * plane], src[(size_t)(2 * 6 + q) * plane], src[(size_t)(3 * 6 + q) * plane],
+          src[(size_t)(4 * 6 + q) * plane], src[(size_t)(5 * 6 + q) * plane], o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r][q] = o[r];
+    }
+    const float sc = scale ? scale[c] : 1.f, sf = shift ? shift[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int oy = 4 * ty + r;
+      if (oy >= H) continue;
+      float o[4];
+      at4(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], s[r][5], o);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ox = 4 * tx + q;
+        if (ox >= W) continue;
+        float v = o[q] * sc + sf;
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[(((size_t)img * H + oy) * W + ox) * ldy + c] = v;
+      }
+    }
+  }
+}
+void launch_wino4_input(const Tensor& x, int th, int tw, float* V, hipStream_t s) {
+  const size_t tiles = (size_t)x.n * th * tw;
+  hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for_w(tiles * x.c)), dim3(256), 0, s, x.p, x.ld, x.n, x.h, x.w, x.c, th, tw, V, tiles * x.c);
+  FE_HIP(hipGetLastError());
+}
+void launch_wino4_output(const float* Mb, const Tensor& y, int th, int tw, const float* scale, const float* shift, int relu, hipStream_t s) {
+  const size_t tiles = (size_t)y.n * th * tw;
+  hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for_w(tiles * y.c)), dim3(256), 0, s, Mb, tiles * y.c, y.n, y.h, y.w, y.c, th, tw, scale, shift, relu, y.p,
+                     y.ld);
+  FE_HIP(hipGetLastError());
+}
+
 }  // namespace fe
