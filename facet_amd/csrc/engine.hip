@@ -225,8 +225,9 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
   // Winograd F(4x4,3x3) (or F(2x2,3x3)) for the deep 3x3 stride-1 layers: input transform -> 36 (16) batched GEMMs in ONE launch
   // -> output transform with the epilogue
   static const bool no_wino = getenv("FE_NO_WINO") != nullptr;
-  if (w.wino && !no_wino && p.variant == 0 && o.sh == 1 && o.sw == 1 && o.ph == 1 && o.pw == 1 && o.dh == 1 && o.dw == 1 && !o.res &&
-      !o.gate && (o.act == ACT_NONE || o.act == ACT_RELU) && y.h == x.h && y.w == x.w && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0 &&
+  const bool wino_plain = !o.res && (o.act == ACT_NONE || o.act == ACT_RELU);     // F(2x2) handles only these; F(4x4) also residual / PReLU
+  if (w.wino && !no_wino && p.variant == 0 && o.sh == 1 && o.sw == 1 && o.ph == 1 && o.pw == 1 && o.dh == 1 && o.dw == 1 &&
+      !o.gate && (wino_plain || (w.wino_m == 4 && (o.act == ACT_NONE || o.act == ACT_RELU || o.act == ACT_PRELU))) && y.h == x.h && y.w == x.w && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0 &&
       x.ld % 4 == 0 && y.ld % 4 == 0) {
     const int ts = w.wino_m, planes = (ts + 2) * (ts + 2);       // output tile side 2 or 4; 16 or 36 planes
     const int th = (x.h + ts - 1) / ts, tw = (x.w + ts - 1) / ts;
@@ -250,7 +251,7 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
       g.batch = planes; g.nb1 = 1; g.xs2 = (long long)tiles * w.Cin; g.ws2 = (long long)w.Cout * w.Cin; g.ys2 = (long long)tiles * w.Cout;
       launch_conv(g, c.stream);
       if (ts == 2) launch_wino_output(Mb, y, th, tw, w.scale, w.shift, o.act == ACT_RELU, c.stream);
-      else launch_wino4_output(Mb, y, th, tw, w.scale, w.shift, o.act == ACT_RELU, c.stream);
+      else launch_wino4_output(Mb, y, th, tw, w.scale, w.shift, o.act, w.slope, o.res, o.res_after_act, c.stream);
       if (c.profile) {   // one record for the three launches, with the direct convolution's FLOPs
         FE_HIP(hipEventRecord(e1, c.stream));
         FE_HIP(hipEventSynchronize(e1));

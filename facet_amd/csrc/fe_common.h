@@ -154,7 +154,8 @@ void launch_conv(const ConvParams& p, hipStream_t s);
 void launch_wino_input(const Tensor& x, int th, int tw, float* V, hipStream_t s);
 void launch_wino_output(const float* Mb, const Tensor& y, int th, int tw, const float* scale, const float* shift, int relu, hipStream_t s);
 void launch_wino4_input(const Tensor& x, int th, int tw, float* V, hipStream_t s);     // F(4x4,3x3): [36][tiles][C] planes
-void launch_wino4_output(const float* Mb, const Tensor& y, int th, int tw, const float* scale, const float* shift, int relu, hipStream_t s);
+void launch_wino4_output(const float* Mb, const Tensor& y, int th, int tw, const float* scale, const float* shift, int act, const float* slope,
+                         const Tensor* res, int res_after_act, hipStream_t s);
 bool launch_stem(const float* x, int ldx, int N, int H, int W, const float* wstem, const float* scale, const float* shift, const float* slope,
                  int Cout, int k, int stride, int act, float* y, int ldy, int Ho, int Wo, hipStream_t s);   // kernels_stem.hip; false = shape not handled
 void launch_conv_narrow(const ConvParams& p, hipStream_t s);            // Cout <= 4, no MFMA (kernels_misc.hip)

@@ -170,8 +170,9 @@ __device__ __forceinline__ void at4(const float m0, const float m1, const float 
   o[3] = m1 - m2 + 8.f * m3 - 8.f * m4 + m5;
 }
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mb, size_t plane, int N, int H, int W, int C, int th, int tw,
-                                                           const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-                                                           float* __restrict__ y, int ldy) {
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                           const float* __restrict__ slope, const float* __restrict__ res, int ldr,
+                                                           int res_after_act, float* __restrict__ y, int ldy) {
   const size_t total = (size_t)N * th * tw * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[r][q] = o[r];
     }
-    const float sc = scale ? scale[c] : 1.f, sf = shift ? shift[c] : 0.f;
+    const float sc = scale ? scale[c] : 1.f, sf = shift ? shift[c] : 0.f, sl = (act == ACT_PRELU) ? slope[c] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int oy = 4 * ty + r;
@@ -200,9 +201,14 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
       for (int q = 0; q < 4; ++q) {
         const int ox = 4 * tx + q;
         if (ox >= W) continue;
+        const size_t pix = ((size_t)img * H + oy) * W + ox;
         float v = o[q] * sc + sf;
-        if (relu) v = v > 0.f ? v : 0.f;
-        y[(((size_t)img * H + oy) * W + ox) * ldy + c] = v;
+        const float rr = res ? res[pix * ldr + c] : 0.f;
+        if (!res_after_act) v += rr;
+        if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (act == ACT_PRELU) v = v > 0.f ? v : v * sl;
+        if (res_after_act) v += rr;
+        y[pix * ldy + c] = v;
       }
     }
   }
@@ -212,10 +218,13 @@ void launch_wino4_input(const Tensor& x, int th, int tw, float* V, hipStream_t s
   hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for_w(tiles * x.c)), dim3(256), 0, s, x.p, x.ld, x.n, x.h, x.w, x.c, th, tw, V, tiles * x.c);
   FE_HIP(hipGetLastError());
 }
-void launch_wino4_output(const float* Mb, const Tensor& y, int th, int tw, const float* scale, const float* shift, int relu, hipStream_t s) {
+void launch_wino4_output(const float* Mb, const Tensor& y, int th, int tw, const float* scale, const float* shift, int act, const float* slope,
+                         const Tensor* res, int res_after_act, hipStream_t s) {
+  FE_CHECK(act == ACT_NONE || act == ACT_RELU || (act == ACT_PRELU && slope), "wino4_output: activation");
+  FE_CHECK(!res || (res->c == y.c && res->pixels() == y.pixels()), "wino4_output: residual shape");
   const size_t tiles = (size_t)y.n * th * tw;
-  hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for_w(tiles * y.c)), dim3(256), 0, s, Mb, tiles * y.c, y.n, y.h, y.w, y.c, th, tw, scale, shift, relu, y.p,
-                     y.ld);
+  hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for_w(tiles * y.c)), dim3(256), 0, s, Mb, tiles * y.c, y.n, y.h, y.w, y.c, th, tw, scale, shift, act,
+                     slope, res ? res->p : nullptr, res ? res->ld : 0, res_after_act, y.p, y.ld);
   FE_HIP(hipGetLastError());
 }
 

@@ -175,3 +175,17 @@ def test_winograd_path_matches_torch(engine, cin, cout, hw, act):
         ref = F.relu(ref)
     ref = ref.numpy()
     assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("res_after", [False, True])
+def test_winograd_with_residual(engine, res_after):
+    """Residual add before / after the activation inside the Winograd output transform (ResNet basic block, IResNet block)."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 128, 11, 9)).astype(np.float32)
+    w = (rng.standard_normal((160, 128, 3, 3)) / np.sqrt(9 * 128)).astype(np.float32)
+    r = rng.standard_normal((2, 160, 11, 9)).astype(np.float32)
+    sh = rng.standard_normal(160).astype(np.float32)
+    got = engine.conv2d(x, w, shift=sh, res=r, res_after_act=res_after, stride=1, pad=1, act="relu")
+    y = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(sh), padding=1)
+    ref = (F.relu(y) + torch.from_numpy(r)) if res_after else F.relu(y + torch.from_numpy(r))
+    assert np.abs(got - ref.numpy()).max() <= 2e-4 * max(1.0, float(ref.abs().max()))
