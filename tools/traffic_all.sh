@@ -9,6 +9,7 @@ for wl in "$@"; do
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${wl}_$c -- python3 $R/bench.py --workload $wl --steps 1 --warmup 1 --batch 32 --cpu-sample 0 > $R/gpurun_out/pmc_${wl}_$c.log 2>&1 || { echo "pass $wl $c failed"; tail -3 $R/gpurun_out/pmc_${wl}_$c.log; exit 1; }
     echo "done $wl $c"
   done
-  python3 $R/tools/collect_traffic.py $R/gpurun_out/pmc_${wl}_FETCH_SIZE $R/gpurun_out/pmc_${wl}_WRITE_SIZE 64 $wl 1024 && cp $R/profiles/r01_traffic.json $R/gpurun_out/r01_traffic.json
+  n=64; [ "$wl" = topiq ] && n=96   # bench.py appends a 32-image per-launch pass for the topiq workload
+  python3 $R/tools/collect_traffic.py $R/gpurun_out/pmc_${wl}_FETCH_SIZE $R/gpurun_out/pmc_${wl}_WRITE_SIZE $n $wl 1024 && cp $R/profiles/r01_traffic.json $R/gpurun_out/r01_traffic.json
   find $R/gpurun_out/pmc_${wl}_FETCH_SIZE $R/gpurun_out/pmc_${wl}_WRITE_SIZE -name "*kernel_trace.csv" -delete
 done
