@@ -232,9 +232,11 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
     const int ts = w.wino_m, planes = (ts + 2) * (ts + 2);       // output tile side 2 or 4; 16 or 36 planes
     const int th = (x.h + ts - 1) / ts, tw = (x.w + ts - 1) / ts;
     const size_t tiles = (size_t)x.n * th * tw;
-    if (tiles < (1u << 30) / 36) {
+    const size_t wino_bytes = (size_t)planes * tiles * ((size_t)w.CinPad + w.Cout) * sizeof(float) + 1024;
+    // falls through to the direct kernel when the two plane buffers do not fit what is left of the arena
+    if (tiles < (1u << 30) / 36 && c.arena.mark() + wino_bytes <= c.arena.capacity()) {
       const size_t mark = c.arena.mark();
-      float* V = (float*)c.arena.alloc((size_t)planes * tiles * w.Cin * sizeof(float));
+      float* V = (float*)c.arena.alloc((size_t)planes * tiles * w.CinPad * sizeof(float));
       float* Mb = (float*)c.arena.alloc((size_t)planes * tiles * w.Cout * sizeof(float));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (c.profile) {
@@ -244,11 +246,12 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
       if (ts == 2) launch_wino_input(x, th, tw, V, c.stream);
       else launch_wino4_input(x, th, tw, V, c.stream);
       ConvParams g{};
-      g.x = V; g.ldx = w.Cin; g.w = w.wino; g.ldw = w.Cin; g.y = Mb; g.ldy = w.Cout;
-      g.M = (int)tiles; g.K = w.Cin; g.Cout = w.Cout;
+      // physical channel count everywhere below: ConvW.Cin may hold the unpadded (algorithmic) count of a graph layer
+      g.x = V; g.ldx = w.CinPad; g.w = w.wino; g.ldw = w.CinPad; g.y = Mb; g.ldy = w.Cout;
+      g.M = (int)tiles; g.K = w.CinPad; g.Cout = w.Cout;
       g.N = 1; g.H = 1; g.W = g.M; g.Ho = 1; g.Wo = g.M; g.KH = g.KW = 1; g.sh = g.sw = g.dh = g.dw = 1;
-      g.Kp = w.Cin; g.Cin = w.Cin;
-      g.batch = planes; g.nb1 = 1; g.xs2 = (long long)tiles * w.Cin; g.ws2 = (long long)w.Cout * w.Cin; g.ys2 = (long long)tiles * w.Cout;
+      g.Kp = w.CinPad; g.Cin = w.CinPad;
+      g.batch = planes; g.nb1 = 1; g.xs2 = (long long)tiles * w.CinPad; g.ws2 = (long long)w.Cout * w.CinPad; g.ys2 = (long long)tiles * w.Cout;
       launch_conv(g, c.stream);
       if (ts == 2) launch_wino_output(Mb, y, th, tw, w.scale, w.shift, o.act == ACT_RELU, c.stream);
       else launch_wino4_output(Mb, y, th, tw, w.scale, w.shift, o.act, w.slope, o.res, o.res_after_act, c.stream);
@@ -264,7 +267,7 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
       }
       c.arena.rewind(mark);
       c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout);   // algorithmic = the direct convolution's
-      c.flops_saved += 2.0 * p.M * (double)(9 * w.Cin) * p.Cout - 2.0 * (double)planes * (double)tiles * w.Cin * w.Cout;
+      c.flops_saved += 2.0 * p.M * (double)(9 * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout) - 2.0 * (double)planes * (double)tiles * w.CinPad * w.Cout;
       return;
     }
   }

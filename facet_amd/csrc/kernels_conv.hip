@@ -305,6 +305,7 @@ static void launch_forced(const ConvParams& q, hipStream_t s) {
 double conv_flops(const ConvParams& p) { return 2.0 * (double)p.M * p.K * p.Cout; }
 
 void launch_conv(const ConvParams& p, hipStream_t s) {
+  FE_CHECK(p.x && p.w && p.y && p.ldy >= p.Cout && p.ldx >= p.Cin, "conv: null operand or row stride below the channel count");
   FE_CHECK(p.Cin % 4 == 0 && p.ldx % 4 == 0, "conv: Cin=%d ldx=%d must be multiples of 4", p.Cin, p.ldx);
   FE_CHECK(((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.w & 15) == 0, "conv: x/w must be 16-B aligned");
   FE_CHECK(p.Kp % CONV_KALIGN == 0 && p.Kp >= p.K, "conv: bad Kp=%d K=%d", p.Kp, p.K);

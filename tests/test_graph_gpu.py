@@ -120,3 +120,17 @@ def test_tensor_encodings_and_legacy_input_lists(engine):
     half = _check(engine, build(np.float16), x)[0]
     half_typed = _check(engine, build(np.float16, encoding="typed"), x)[0]
     assert np.allclose(half, half_typed, rtol=1e-6, atol=1e-7) and np.abs(half - base).max() < 0.05 * np.abs(base).max()
+
+
+def test_winograd_inside_graphs_with_padded_channels(engine):
+    """3x3 convs of a graph whose channel counts are not multiples of 16 (150 -> physical 160, 200 -> 208): the Winograd path must
+    work on the physical (padded) layout; with a residual Add + Relu and a PRelu behind them."""
+    g = W.GraphBuilder(44)
+    a = g.relu(g.conv("x", 3, 150, 3, 1))
+    b = g.conv(a, 150, 150, 3, 1)                      # Cin 150 (pad 160): Winograd, residual + relu fused into the output transform
+    c = g.relu(g.add(b, a))
+    d = g.prelu(g.conv(c, 150, 200, 3, 1), 200)        # PRelu epilogue
+    e = g.conv(d, 200, 24, 3, 1)                       # physical Cin 208: not a multiple of 32 -> direct kernel
+    data = g.build([("x", ["N", 3, 21, 30])], [(e, ["N", 24, 21, 30]), (c, ["N", 150, 21, 30])])
+    x = np.random.default_rng(2).uniform(-1, 1, (2, 3, 21, 30)).astype(np.float32)
+    _check(engine, data, x)
