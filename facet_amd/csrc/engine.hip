@@ -88,7 +88,7 @@ ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>
       c.wstem = dw.upload(st);
     }
   }
-  static const int wino_min_cin = getenv("FE_WINO_MIN_CIN") ? atoi(getenv("FE_WINO_MIN_CIN")) : 128;   // tuning hooks; defaults measured best (profiles/r01_README.md)
+  static const int wino_min_cin = getenv("FE_WINO_MIN_CIN") ? atoi(getenv("FE_WINO_MIN_CIN")) : 96;   // tuning hooks; defaults measured best (profiles/r01_README.md)
   static const int wino_form = getenv("FE_WINO_FORM") ? atoi(getenv("FE_WINO_FORM")) : 4;
   if ((wino_form == 2 || wino_form == 4) && c.KH == 3 && c.KW == 3 && c.Cin == c.CinPad && c.Cin % 32 == 0 && c.Cin >= wino_min_cin && c.Cout % 4 == 0) {
     // Winograd weights U = G g G^T per (cout, cin), in double. Layout [planes][Cout][Cin]; the epilogue scale / shift / activation
