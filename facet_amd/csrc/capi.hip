@@ -128,7 +128,14 @@ int fe_create(int device, size_t arena_bytes, fe_ctx** out) {
     auto* x = new fe_ctx();
     x->c.device = device;
     FE_HIP(hipStreamCreateWithFlags(&x->c.stream, hipStreamNonBlocking));
-    x->c.arena.init(arena_bytes ? arena_bytes : ((size_t)8 << 30));
+    if (!arena_bytes) {
+      // default workspace: a quarter of the free HBM, capped at 64 GiB (8 x 1024^2 images of TOPIQ in flight need ~13 GB,
+      // 128 SAMP crops ~20 GB); on a 288 GB MI355X that is 64 GiB. Pass an explicit size to override.
+      size_t free_b = 0, total_b = 0;
+      FE_HIP(hipMemGetInfo(&free_b, &total_b));
+      arena_bytes = std::min<size_t>((size_t)64 << 30, std::max<size_t>((size_t)2 << 30, free_b / 4));
+    }
+    x->c.arena.init(arena_bytes);
     FE_HIP(hipEventCreate(&x->t0));
     FE_HIP(hipEventCreate(&x->t1));
     *out = x;

@@ -49,7 +49,7 @@ enum fe_act { FE_ACT_NONE = 0, FE_ACT_RELU = 1, FE_ACT_GELU = 2, FE_ACT_SIGMOID 
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 /* Creates a context on HIP device `device` with a workspace arena of `arena_bytes`
- * (0 = default 8 GiB). Fails (no CPU fallback) when no gfx950 device is present. */
+ * (0 = a quarter of the free HBM, at most 64 GiB). Fails (no CPU fallback) when no gfx950 device is present. */
 int fe_create(int device, size_t arena_bytes, fe_ctx** out);
 void fe_destroy(fe_ctx* ctx);
 const char* fe_last_error(fe_ctx* ctx); /* ctx may be NULL: returns the last fe_create error */

@@ -77,3 +77,15 @@ def test_face_detect_fullsize_vs_oracle(big_engine):
     assert [len(f) for f in faces] == [min(g[0].shape[0], 512) for g in got]
     assert all(np.array_equal(f[0].bbox, g[0][0, :4]) for f, g in zip(faces, got))
     fe.unload()
+
+
+def test_default_context_handles_fullsize_batches():
+    """Engine(0) with no arena size and the default micro-batch (what the mirrors create on their own) must score 1024x1024 batches:
+    the default workspace is sized from the free HBM, not a fixed small slab."""
+    from facet_amd import Engine
+    e = Engine(0)
+    e.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", seed=3))
+    imgs = synthetic_images(9, 9, HW, HW)
+    s = e.topiq_score(imgs)
+    assert s.shape == (9,) and np.isfinite(s).all()
+    e.close()
