@@ -8,15 +8,18 @@ Each dict carries, under the reference's own key names (batch_processor.py:298-3
 a pixel scan: CLIP aesthetic + embedding blob, TOPIQ quality, SAMP-Net composition score / pattern, the face dict's fields,
 the seven technical-metric groups, tags, and the two cross terms the reference derives on the spot (face_ratio :244,
 isolation_bonus :264-269). What stays with the caller because it needs files, configuration policy or libraries outside the
-hot path: path / EXIF columns, phash (imagehash), leading lines (CompositionAnalyzer.detect_leading_lines),
-category / aggregate (`Facet.calculate_aggregate_logic`, configuration policy) - `metrics_for_aggregate()` returns
-the exact `metrics` mapping that function expects (:272-296) with those caller-side fields left as given.
+hot path: path / EXIF columns, phash (imagehash), leading lines (CompositionAnalyzer.detect_leading_lines: Canny + probabilistic
+Hough in OpenCV; pass `leading_lines=` scores in if you have them). With `policy=` (an `aggregate.AggregatePolicy` made from the
+scoring configuration) the category and aggregate score (`Facet.calculate_aggregate_logic`) are computed for the whole batch
+as the last step, from the multi-pass metrics mapping (multi_pass.py:713-752); `metrics_for_aggregate()` returns the
+narrower mapping of the single-pass path (batch_processor.py:272-296).
 
 Engine calls per batch: fe_ensemble_score (TOPIQ + CLIP + aesthetic + U2-Net-P + SAMP-Net), fe_image_stats (technical scans),
 fe_face_analyze + fe_roi_laplacian (through FaceAnalyzer.analyze_faces_batch), fe_tag_similarities (through CLIPTagger).
 """
 import numpy as np
 
+from .aggregate import aggregate_batch
 from .image_stats import TechnicalAnalyzer
 from .samp_net import postprocess as samp_postprocess
 
@@ -53,14 +56,16 @@ def detect_silhouette(histogram_silhouette, tags, face_count):
 
 class BatchScorer:
     def __init__(self, engine, tagger=None, face_analyzer=None, tag_threshold=0.22, max_tags=5, mono_threshold=0.10,
-                 shadow_threshold=0.15, highlight_threshold=0.10, power_weight=2.0, line_weight=1.0):
-        self.engine, self.tagger, self.face_analyzer = engine, tagger, face_analyzer
+                 shadow_threshold=0.15, highlight_threshold=0.10, power_weight=2.0, line_weight=1.0, policy=None):
+        self.engine, self.tagger, self.face_analyzer, self.policy = engine, tagger, face_analyzer, policy
         self.power_weight, self.line_weight = power_weight, line_weight
         self.tag_threshold, self.max_tags = tag_threshold, max_tags           # utils/tags.py:50-51 defaults
         self.mono_threshold, self.shadow_threshold, self.highlight_threshold = mono_threshold, shadow_threshold, highlight_threshold
 
-    def process_batch(self, images_rgb):
-        """images_rgb: uint8 [n,h,w,3] (the PIL images of a batch as one array). Returns one dict per image."""
+    def process_batch(self, images_rgb, exif=None, leading_lines=None):
+        """images_rgb: uint8 [n,h,w,3] (the PIL images of a batch as one array). Returns one dict per image. exif: optional list
+        of per-image dicts (iso / f_stop / shutter_speed / focal_length) and leading_lines: optional per-image
+        leading_lines_score, both only used by the aggregate step (policy given)."""
         imgs = np.ascontiguousarray(images_rgb, dtype=np.uint8)
         n, h, w, _ = imgs.shape
         bgr = np.ascontiguousarray(imgs[..., ::-1])                          # img_cv of the reference
@@ -114,8 +119,33 @@ class BatchScorer:
             res['power_point_score'] = float(comp['power_point_score'])
             res.setdefault('comp_score', round(comp['score'], 2))
             res['is_silhouette'] = detect_silhouette(t['histogram'].get('is_silhouette', 0), res.get('tags'), res.get('face_count', 0))
+            if leading_lines is not None:
+                res['leading_lines_score'] = float(leading_lines[i])
             out.append(res)
+        if self.policy is not None:
+            rows = [self.metrics_multi_pass(r, exif[i] if exif else None) for i, r in enumerate(out)]
+            scores, cats = aggregate_batch(rows, self.policy)
+            for r, s, c in zip(out, scores.tolist(), cats):
+                r['aggregate'], r['category'] = s, c
         return out
+
+    @staticmethod
+    def metrics_multi_pass(res, exif=None):
+        """The `metrics` mapping of the multi-pass path (multi_pass.py:713-752) from a process_batch dict."""
+        exif = exif or {}
+        return {
+            'aesthetic': res.get('aesthetic', 5.0), 'quality_score': res.get('quality_score'), 'scoring_model': res.get('scoring_model', 'clip-mlp'),
+            'comp_score': res.get('comp_score', 5.0), 'face_count': res.get('face_count', 0), 'face_quality': res.get('face_quality', 0),
+            'eye_sharpness': res.get('eye_sharpness', 0), 'face_sharpness': res.get('face_sharpness', 0), 'tech_sharpness': res['tech_sharpness'],
+            'color_score': res['color_score'], 'exposure_score': res['exposure_score'], 'face_ratio': res.get('face_ratio', 0),
+            'tags': res.get('tags') or '', 'isolation_bonus': res.get('_isolation_bonus_raw', 1.0), 'is_blink': res.get('is_blink', 0),
+            'is_group_portrait': res.get('is_group_portrait', 0), 'shadow_clipped': res['shadow_clipped'], 'highlight_clipped': res['highlight_clipped'],
+            'is_silhouette': res.get('is_silhouette', 0), 'histogram_spread': res['histogram_spread'], 'histogram_bimodality': res['histogram_bimodality'],
+            'mean_luminance': res['mean_luminance'], 'is_monochrome': res['is_monochrome'], 'mean_saturation': res['mean_saturation'],
+            'contrast_score': res['contrast_score'], 'noise_sigma': res['noise_sigma'], 'leading_lines_score': res.get('leading_lines_score', 0),
+            'power_point_score': res.get('power_point_score', 5.0), 'topiq_score': res.get('quality_score'),
+            'iso': exif.get('iso'), 'f_stop': exif.get('f_stop'), 'shutter_speed': exif.get('shutter_speed'), 'focal_length': exif.get('focal_length'),
+        }
 
     @staticmethod
     def metrics_for_aggregate(res, exif=None, is_silhouette=None, comp_score=None):

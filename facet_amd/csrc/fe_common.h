@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -27,6 +28,17 @@ struct Error : std::runtime_error {
       throw fe::Error(_b);                                                                \
     }                                                                                     \
   } while (0)
+
+// hipFuncSetAttribute applies to the CURRENT device only; `done` (one per kernel instantiation) keeps a bit per device ordinal,
+// so a process that drives several GPUs (one context each) raises the dynamic-LDS limit on each of them once.
+inline void ensure_dynamic_lds(const void* kernel, size_t bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  FE_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  FE_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  done.fetch_or(bit, std::memory_order_release);
+}
 
 #define FE_CHECK(cond, ...)                                                               \
   do {                                                                                    \

@@ -279,11 +279,8 @@ static void launch_variant(const ConvParams& p, hipStream_t s) {
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
   const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
   auto kern = conv_igemm_kernel<WGM, WGN, TM, TN, BK, FAST>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    FE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_set{0};
+  ensure_dynamic_lds((const void*)kern, lds, lds_set);
   hipLaunchKernelGGL(kern, dim3(mtiles * ntiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, ntiles);
   FE_HIP(hipGetLastError());
 }

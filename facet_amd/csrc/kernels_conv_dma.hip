@@ -321,11 +321,8 @@ static void launch_dma_variant(const ConvParams& p, hipStream_t s) {
   constexpr size_t epi_lds = (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   auto kern = conv_dma_kernel<WGM, WGN, TM, TN, MODE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    FE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_set{0};
+  ensure_dynamic_lds((const void*)kern, lds, lds_set);
   hipLaunchKernelGGL(kern, dim3(mtiles * ntiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, ntiles);
   FE_HIP(hipGetLastError());
 }

@@ -229,11 +229,8 @@ void launch_image_stats(const uint8_t* bgr, int n, int h, int w, uint8_t* gray, 
   StatsAccum* acc = (StatsAccum*)accum;
   FE_HIP(hipMemsetAsync(acc, 0, stats_accum_bytes(n), s));
   constexpr size_t lds = (size_t)(90 * 256 + 256 + 512) * sizeof(unsigned int);
-  static bool attr_set = false;
-  if (!attr_set) {
-    FE_HIP(hipFuncSetAttribute((const void*)stats_pass1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_set{0};
+  ensure_dynamic_lds((const void*)stats_pass1_kernel, lds, lds_set);
   hipLaunchKernelGGL(stats_pass1_kernel, dim3(2, n), dim3(1024), lds, s, bgr, h, w, gray, hsv_out, sdiv, hdiv, acc);
   FE_HIP(hipGetLastError());
   const int rpb = 16;

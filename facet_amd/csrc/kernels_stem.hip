@@ -116,8 +116,8 @@ template <int TN, int K, int S>
 static void launch_stem_t(const StemParams& p, hipStream_t s) {
   constexpr int PH = (STEM_TH - 1) * S + K, PW = (STEM_TW - 1) * S + K, T2 = (K * K + 1) & ~1;
   constexpr size_t lds = ((size_t)PH * PW * 4 + (size_t)TN * 32 * T2 * 4) * sizeof(float);
-  static bool attr = false;
-  if (!attr) { FE_HIP(hipFuncSetAttribute((const void*)stem_kernel<TN, K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  static std::atomic<uint64_t> lds_set{0};
+  ensure_dynamic_lds((const void*)stem_kernel<TN, K, S>, lds, lds_set);
   const dim3 grid((p.Wo + STEM_TW - 1) / STEM_TW, (p.Ho + STEM_TH - 1) / STEM_TH, p.N);
   hipLaunchKernelGGL((stem_kernel<TN, K, S>), grid, dim3(256), lds, s, p);
   FE_HIP(hipGetLastError());

@@ -58,5 +58,14 @@ def test_process_batch_equals_per_model_calls():
         assert r['tags'] is not None and len(r['tags'].split(',')) == 2
         m = BatchScorer.metrics_for_aggregate(r, exif={'iso': 400, 'f_stop': 2.8})
         assert m['aesthetic'] == r['aesthetic'] and m['iso'] == 400 and m['comp_score'] == r['comp_score'] and m['quality_score'] == r['quality_score']
+    # the aggregate step: whole-batch epilogue == the per-image function on the multi-pass mapping
+    import json, os
+    from facet_amd.aggregate import AggregatePolicy, aggregate
+    pol = AggregatePolicy(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "aggregate_golden.json")))["rich"]["config"])
+    exif = [{'iso': 64, 'f_stop': 1.8, 'shutter_speed': '1/1000', 'focal_length': 300}] * 5
+    out2 = BatchScorer(e, tagger=tg, face_analyzer=fa, tag_threshold=-1.0, max_tags=2, policy=pol).process_batch(imgs, exif=exif, leading_lines=[0, 1, 2, 3, 4])
+    for r, r2, x in zip(out, out2, exif):
+        assert (r2['aggregate'], r2['category']) == aggregate(BatchScorer.metrics_multi_pass(r2, x), pol)
+        assert 0.0 <= r2['aggregate'] <= 10.0 and all(r2[k] == r[k] for k in r)
     fa.face_app.unload()
     e.close()
