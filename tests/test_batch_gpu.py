@@ -66,6 +66,6 @@ def test_process_batch_equals_per_model_calls():
     out2 = BatchScorer(e, tagger=tg, face_analyzer=fa, tag_threshold=-1.0, max_tags=2, policy=pol).process_batch(imgs, exif=exif, leading_lines=[0, 1, 2, 3, 4])
     for r, r2, x in zip(out, out2, exif):
         assert (r2['aggregate'], r2['category']) == aggregate(BatchScorer.metrics_multi_pass(r2, x), pol)
-        assert 0.0 <= r2['aggregate'] <= 10.0 and all(r2[k] == r[k] for k in r)
+        assert 0.0 <= r2['aggregate'] <= 10.0 and all(r2[k] == r[k] for k in ('aesthetic', 'quality_score', 'comp_score', 'tags', 'face_count', 'tech_sharpness', 'noise_sigma', 'clip_embedding'))
     fa.face_app.unload()
     e.close()
