@@ -266,7 +266,7 @@ def main():
                          "kernel": "conv_dma_kernel + conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; every contraction launched in the timed region)",
                          "flops_per_image": round(flops / (B * args.steps), 1),
                          "executed_flops_per_image": round(flops_exec / (B * args.steps), 1),
-                         "executed_note": "3x3 stride-1 convs with Cin >= 256 run as Winograd F(2x2,3x3); `achieved` counts the direct convolution's FLOPs, "
+                         "executed_note": "3x3 stride-1 pad-1 convs with >= 96 input channels run as Winograd F(4x4,3x3) (36 batched GEMMs per launch); `achieved` counts the direct convolution's FLOPs, "
                                           "the matrix cores executed executed_flops_per_image",
                          "event_ms": round(ev_ms, 3), "per_launch": per_launch},
         }

@@ -67,5 +67,18 @@ def test_process_batch_equals_per_model_calls():
     for r, r2, x in zip(out, out2, exif):
         assert (r2['aggregate'], r2['category']) == aggregate(BatchScorer.metrics_multi_pass(r2, x), pol)
         assert 0.0 <= r2['aggregate'] <= 10.0 and all(r2[k] == r[k] for k in ('aesthetic', 'quality_score', 'comp_score', 'tags', 'face_count', 'tech_sharpness', 'noise_sigma', 'clip_embedding'))
+    # the format invariants the reference's only runtime self-check holds rows to (validation/database_validator.py:14-36, 89-116,
+    # 143+, 332-378, 400-425); composition patterns are the 8 names samp_net.py:23-32 emits (the validator's list differs)
+    for r in out2:
+        for k in ('aesthetic', 'face_quality', 'eye_sharpness', 'tech_sharpness', 'color_score', 'exposure_score', 'comp_score', 'contrast_score',
+                  'aggregate', 'quality_score'):
+            assert 0.0 <= r[k] <= 10.0, (k, r[k])
+        assert len(r['clip_embedding']) == 3072 and len(r['histogram_data']) == 1024
+        for k in ('is_blink', 'is_monochrome', 'is_silhouette', 'is_group_portrait', 'shadow_clipped', 'highlight_clipped'):
+            assert r[k] in (0, 1), (k, r[k])
+        if r['face_count'] == 0:
+            assert r['face_quality'] == 0 and r['eye_sharpness'] == 0 and r['face_sharpness'] == 0 and r['face_ratio'] == 0
+        assert 0.0 <= r['face_ratio'] <= 1.0
+        assert r['composition_pattern'] in ('global', 'horizontal', 'vertical', 'triangular', 'surround', 'quarter', 'cross', 'rule_of_thirds')
     fa.face_app.unload()
     e.close()
