@@ -104,6 +104,8 @@ SIGNATURES = {
     "fe_roi_laplacian": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_double)]),
     "fe_cv_resize_linear_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "fe_leading_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -523,6 +525,27 @@ class Engine:
         self._ck(self.lib.fe_roi_laplacian(self.h, p, n, h, w, dev, idx.shape[0], idx.ctypes.data_as(C.POINTER(C.c_int)),
                                            r.ctypes.data_as(C.POINTER(C.c_int)), out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
+
+    def leading_lines(self, images, canny_low=50, canny_high=150, threshold=80, min_line_length=None, max_line_gap=20, max_lines=2048,
+                      want_edges=False):
+        """BGR uint8 batch -> list of int32 [k,4] segment arrays (x1,y1,x2,y2; what cv2.HoughLinesP(cv2.Canny(cv2.GaussianBlur(gray,
+        (5,5), 0), low, high), 1, pi/180, threshold, minLineLength, maxLineGap) returns per image, in the order found), and the
+        Canny edge images uint8 [n,h,w] when want_edges. min_line_length defaults to int(min(h, w) * 0.15) (composition.py:219)."""
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        if min_line_length is None:
+            min_line_length = int(min(h, w) * 0.15)
+        edges = np.empty((n, h, w), np.uint8) if want_edges else None
+        while True:
+            lines = np.zeros((n, max_lines, 4), np.int32)
+            counts = np.zeros(n, np.int32)
+            self._ck(self.lib.fe_leading_lines(self.h, p, n, h, w, dev, canny_low, canny_high, threshold, min_line_length, max_line_gap, max_lines,
+                                               lines.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p),
+                                               edges.ctypes.data_as(C.c_void_p) if want_edges else None))
+            if int(counts.max()) <= max_lines:
+                break
+            max_lines = int(counts.max())          # rare: more segments than room - run again with enough
+        out = [lines[i, :counts[i]].copy() for i in range(n)]
+        return (out, edges) if want_edges else out
 
     def cv_resize_linear(self, imgs, oh, ow):
         a = np.ascontiguousarray(imgs, dtype=np.uint8)

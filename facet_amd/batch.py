@@ -9,7 +9,7 @@ a pixel scan: CLIP aesthetic + embedding blob, TOPIQ quality, SAMP-Net compositi
 the seven technical-metric groups, tags, and the two cross terms the reference derives on the spot (face_ratio :244,
 isolation_bonus :264-269). What stays with the caller because it needs files, configuration policy or libraries outside the
 hot path: path / EXIF columns, phash (imagehash), leading lines (CompositionAnalyzer.detect_leading_lines: Canny + probabilistic
-Hough in OpenCV; pass `leading_lines=` scores in if you have them). With `policy=` (an `aggregate.AggregatePolicy` made from the
+Hough; `detect_lines=True` computes them through `fe_leading_lines`, or pass `leading_lines=` scores in). With `policy=` (an `aggregate.AggregatePolicy` made from the
 scoring configuration) the category and aggregate score (`Facet.calculate_aggregate_logic`) are computed for the whole batch
 as the last step, from the multi-pass metrics mapping (multi_pass.py:713-752); `metrics_for_aggregate()` returns the
 narrower mapping of the single-pass path (batch_processor.py:272-296).
@@ -56,8 +56,8 @@ def detect_silhouette(histogram_silhouette, tags, face_count):
 
 class BatchScorer:
     def __init__(self, engine, tagger=None, face_analyzer=None, tag_threshold=0.22, max_tags=5, mono_threshold=0.10,
-                 shadow_threshold=0.15, highlight_threshold=0.10, power_weight=2.0, line_weight=1.0, policy=None):
-        self.engine, self.tagger, self.face_analyzer, self.policy = engine, tagger, face_analyzer, policy
+                 shadow_threshold=0.15, highlight_threshold=0.10, power_weight=2.0, line_weight=1.0, policy=None, detect_lines=False):
+        self.engine, self.tagger, self.face_analyzer, self.policy, self.detect_lines = engine, tagger, face_analyzer, policy, detect_lines
         self.power_weight, self.line_weight = power_weight, line_weight
         self.tag_threshold, self.max_tags = tag_threshold, max_tags           # utils/tags.py:50-51 defaults
         self.mono_threshold, self.shadow_threshold, self.highlight_threshold = mono_threshold, shadow_threshold, highlight_threshold
@@ -75,6 +75,9 @@ class BatchScorer:
         tags = None
         if self.tagger is not None and self.tagger.text_embeddings is not None and mask & 2:
             tags = self.tagger.get_tags_batch(rec[:, 21:789], self.engine, self.tag_threshold, self.max_tags)
+        if leading_lines is None and self.detect_lines:      # CompositionAnalyzer.detect_leading_lines (multi_pass.py:702-705), batched
+            from .composition import score_lines
+            leading_lines = [score_lines(l, h, w)['leading_lines_score'] for l in self.engine.leading_lines(bgr)]
         out = []
         for i in range(n):
             t = tech[i]

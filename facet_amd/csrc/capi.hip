@@ -1,5 +1,7 @@
 // C ABI of libfacet_engine.so (declared in include/facet_engine.h).
 #include "../../include/facet_engine.h"
+#include <thread>
+
 #include "engine.h"
 #include "onnx_graph.h"
 #include <algorithm>
@@ -1538,6 +1540,40 @@ int fe_roi_laplacian(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int o
   launch_roi_laplacian(d_img, h, w, d_idx, d_roi, m, d_out, C.stream);
   FE_HIP(hipMemcpyAsync(out, d_out, (size_t)m * 4 * sizeof(double), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+/* Leading lines (reference analyzers/composition.py:191-261): blur + Canny map on the GPU, hysteresis + probabilistic Hough per image on host threads */
+int fe_leading_lines(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, int canny_low, int canny_high, int threshold,
+                     int min_line_length, int max_line_gap, int max_lines, int* lines, int* counts, uint8_t* edges_out) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(bgr && n > 0 && h > 0 && w > 0 && (size_t)h * w < (1ull << 30), "bad arguments");
+  FE_CHECK((lines != nullptr) == (counts != nullptr) && (lines || edges_out), "pass lines AND counts, and / or edges_out");
+  FE_CHECK(!lines || max_lines > 0, "max_lines must be positive");
+  FE_CHECK(canny_low >= 0 && canny_high >= canny_low && threshold > 0 && min_line_length >= 0 && max_line_gap >= 0, "bad thresholds");
+  const size_t npx = (size_t)h * w, per = npx * 3;
+  const int mb = std::max(1, std::min(n, 64));
+  const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<uint8_t> scratch;
+  if (!edges_out) scratch.resize((size_t)mb * npx);
+  ImageStager st(ctx, bgr, n, per, mb, on_device);
+  for (int k = 0; k < st.chunks(); ++k) {
+    const int i0 = k * mb, nb = st.count(k);
+    C.arena.reset();
+    const uint8_t* d_in = st.get(k);
+    uint8_t* d_blur = (uint8_t*)C.arena.alloc((size_t)nb * npx);
+    void* d_grad = C.arena.alloc((size_t)nb * npx * 4);
+    void* d_mag = C.arena.alloc((size_t)nb * npx * 2);
+    uint8_t* d_map = (uint8_t*)C.arena.alloc((size_t)nb * npx);
+    launch_canny_map(d_in, nb, h, w, canny_low, canny_high, d_blur, d_grad, d_mag, d_map, C.stream);
+    st.done(k);
+    uint8_t* maps = edges_out ? edges_out + (size_t)i0 * npx : scratch.data();
+    FE_HIP(hipMemcpyAsync(maps, d_map, (size_t)nb * npx, hipMemcpyDeviceToHost, C.stream));
+    FE_HIP(hipStreamSynchronize(C.stream));
+    lines_host_stage(maps, nb, h, w, threshold, min_line_length, max_line_gap, max_lines, lines ? lines + (size_t)i0 * max_lines * 4 : nullptr,
+                     counts ? counts + i0 : nullptr, threads);
+  }
   FE_API_END(ctx)
 }
 

@@ -243,6 +243,17 @@ int fe_image_stats(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_
 int fe_roi_laplacian(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, int m, const int* img_index, const int* rois,
                      double* out);
 
+/* Leading lines (last item): the reference's CompositionAnalyzer.detect_leading_lines (analyzers/composition.py:191-261)
+ * runs cv2.GaussianBlur(gray, (5,5), 0), cv2.Canny(blurred, 50, 150) and cv2.HoughLinesP(edges, 1, pi/180, 80, minLineLength =
+ * int(min(h,w)*0.15), maxLineGap = 20) per image on the CPU. Here the pixel scans (gray, 5x5 fixed-point blur, Sobel, L1 magnitude,
+ * non-maximum suppression + thresholds) run on the GPU over the BGR batch; hysteresis and the progressive probabilistic Hough
+ * transform (rho 1 px, theta 1 degree; a sequential, pseudo-random-order vote-and-erase loop) run on the host, one image per
+ * thread. lines [n][max_lines][4] = x1,y1,x2,y2 in the order found, counts [n] = segments found per image (may exceed max_lines:
+ * only the first max_lines are stored - call again with more room); both nullable together. edges_out [n][h][w] (nullable, host)
+ * receives the Canny edge image (0 / 255). facet_amd/composition.py scores the segments as the reference does. */
+int fe_leading_lines(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, int canny_low, int canny_high, int threshold,
+                     int min_line_length, int max_line_gap, int max_lines, int* lines, int* counts, uint8_t* edges_out);
+
 #ifdef __cplusplus
 }
 #endif

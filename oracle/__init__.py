@@ -16,7 +16,7 @@ Pinning status (see DESIGN.md "Oracle"):
     reference's code path, but independent code): the ResNet-50 pyramid and both CLIP towers equal HuggingFace
     transformers' implementations with the same weights (tests/test_oracle_second_opinion.py); the CFANet head has none.
   * ONNX graph evaluation (oracle/onnx_ref.py), face pre/post-processing (oracle/face_ref.py), technical metrics
-    (oracle/technical_ref.py): restate ONNX operator semantics / insightface / OpenCV fixed-point arithmetic
+    (oracle/technical_ref.py), leading lines (oracle/lines_ref.py: Gaussian / Canny / probabilistic Hough): restate ONNX operator semantics / insightface / OpenCV fixed-point arithmetic
     [DEP-KNOWLEDGE]; onnxruntime, insightface, cv2 and the buffalo_l files are absent -> "parity unpinned"; the OpenCV
-    pieces are held to known answers in tests/test_cv_semantics.py.
+    pieces are held to known answers in tests/test_cv_semantics.py and tests/test_lines_host.py.
 """

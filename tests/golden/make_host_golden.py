@@ -135,6 +135,34 @@ for hs in (0, 1):
             sil.append({"hist": hs, "tags": tags, "faces": fc, "out": detect_silhouette({"is_silhouette": hs}, tags, fc)})
 out["silhouette"] = sil
 
+# ---- CompositionAnalyzer.detect_leading_lines segment scoring + integrate_leading_lines (analyzers/composition.py:231-283) ----------
+# cv2 is absent: its four calls in that function are mocked on the stub module - the three image operations pass their input
+# through and HoughLinesP hands back the segment array prescribed here, so what is pinned is the scoring that follows them.
+import analyzers.composition as ref_comp               # noqa: E402
+cvm = ref_comp.cv2
+cvm.COLOR_BGR2GRAY = 6
+cvm.cvtColor = lambda img, code: img[..., 0]
+cvm.GaussianBlur = lambda g, k, s: g
+cvm.Canny = lambda g, lo, hi: g
+ll = []
+for k in range(10):
+    h_, w_ = int(rng.integers(100, 1500)), int(rng.integers(100, 1500))
+    nl = [0, 1, 2, 5, 17, 40, 3, 8, 1, 60][k]
+    segs = None
+    if nl:
+        segs = np.stack([rng.integers(0, w_, nl), rng.integers(0, h_, nl), rng.integers(0, w_, nl), rng.integers(0, h_, nl)], 1).astype(np.int32)
+        if k % 2:
+            segs[0, 2] = segs[0, 0]                     # a vertical segment (the x2 == x1 branch)
+        if k == 5:
+            segs[1] = [10, 10, 10 + 100, 10 + 100]       # exactly 45 degrees
+    cvm.HoughLinesP = lambda e, rho, theta, thr, minLineLength=0, maxLineGap=0, _s=segs: None if _s is None else _s[:, None, :].copy()
+    res = CompositionAnalyzer.detect_leading_lines(np.zeros((h_, w_, 3), np.uint8))
+    ll.append({"h": h_, "w": w_, "lines": None if segs is None else segs.tolist(),
+               "out": {"leading_lines_score": float(res["leading_lines_score"]), "line_count": int(res["line_count"])}})
+out["leading_lines_scoring"] = ll
+out["integrate_leading_lines"] = [{"base": b, "lines": l, "faces": f, "out": float(CompositionAnalyzer.integrate_leading_lines(b, l, f))}
+                                  for b in (0.0, 4.5, 9.2, 10.0) for l in (0.0, 3.3, 10.0, 25.0) for f in (False, True)]
+
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_golden.json")
 json.dump(out, open(path, "w"))
 print("wrote", path, os.path.getsize(path), "bytes")

@@ -114,3 +114,14 @@ def test_detect_silhouette_matches_reference():
     from facet_amd.batch import detect_silhouette
     for c in G["silhouette"]:
         assert detect_silhouette(c["hist"], c["tags"], c["faces"]) == c["out"], c
+
+
+def test_leading_line_scoring_matches_reference():
+    """Segment scoring of detect_leading_lines and integrate_leading_lines (analyzers/composition.py:231-283), golden made with the
+    reference's function and its cv2 calls mocked to return the stored segments."""
+    from facet_amd.composition import CompositionAnalyzer, score_lines
+    for c in G["leading_lines_scoring"]:
+        got = score_lines(None if c["lines"] is None else np.array(c["lines"], np.int32), c["h"], c["w"])
+        assert float(got["leading_lines_score"]) == c["out"]["leading_lines_score"] and got["line_count"] == c["out"]["line_count"], c
+    for c in G["integrate_leading_lines"]:
+        assert CompositionAnalyzer.integrate_leading_lines(c["base"], c["lines"], c["faces"]) == c["out"]
