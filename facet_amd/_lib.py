@@ -104,6 +104,7 @@ SIGNATURES = {
     "fe_roi_laplacian": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_double)]),
     "fe_cv_resize_linear_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "fe_swap_rb_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "fe_leading_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -525,6 +526,15 @@ class Engine:
         self._ck(self.lib.fe_roi_laplacian(self.h, p, n, h, w, dev, idx.shape[0], idx.ctypes.data_as(C.POINTER(C.c_int)),
                                            r.ctypes.data_as(C.POINTER(C.c_int)), out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
+
+    def swap_rb(self, src, pixels, dst_device):
+        """dst_device (device pointer) <- src (host uint8 array or device pointer) with R and B exchanged, `pixels` 3-byte pixels."""
+        if isinstance(src, np.ndarray):
+            a = np.ascontiguousarray(src, dtype=np.uint8)
+            assert a.size == pixels * 3
+            self._ck(self.lib.fe_swap_rb_u8(self.h, a.ctypes.data_as(C.c_void_p), 0, pixels, dst_device))
+        else:
+            self._ck(self.lib.fe_swap_rb_u8(self.h, src, 1, pixels, dst_device))
 
     def leading_lines(self, images, canny_low=50, canny_high=150, threshold=80, min_line_length=None, max_line_gap=20, max_lines=2048,
                       want_edges=False):

@@ -68,16 +68,27 @@ class BatchScorer:
         leading_lines_score, both only used by the aggregate step (policy given)."""
         imgs = np.ascontiguousarray(images_rgb, dtype=np.uint8)
         n, h, w, _ = imgs.shape
-        bgr = np.ascontiguousarray(imgs[..., ::-1])                          # img_cv of the reference
-        rec, mask = self.engine.ensemble_score(imgs)
-        tech = TechnicalAnalyzer.analyze_batch(self.engine, bgr, self.shadow_threshold, self.highlight_threshold, self.mono_threshold)
-        faces = self.face_analyzer.analyze_faces_batch(list(bgr)) if (self.face_analyzer is not None and self.face_analyzer.available) else None
+        # one upload; the BGR copy the reference keeps as img_cv is made on the device, and every engine call reads the resident batch
+        e = self.engine
+        d_rgb, d_bgr = e.dev_alloc(imgs.nbytes), e.dev_alloc(imgs.nbytes)
+        try:
+            e.h2d(d_rgb, imgs)
+            e.swap_rb(d_rgb, n * h * w, d_bgr)
+            rgb_dev, bgr_dev = (d_rgb, n, h, w), (d_bgr, n, h, w)
+            rec, mask = e.ensemble_score(rgb_dev)
+            tech = TechnicalAnalyzer.analyze_batch(e, bgr_dev, self.shadow_threshold, self.highlight_threshold, self.mono_threshold)
+            faces = None
+            if self.face_analyzer is not None and self.face_analyzer.available:
+                faces = self.face_analyzer.analyze_faces_batch([imgs[i][..., ::-1] for i in range(n)], resident=bgr_dev)
+            if leading_lines is None and self.detect_lines:      # CompositionAnalyzer.detect_leading_lines (multi_pass.py:702-705), batched
+                from .composition import score_lines
+                leading_lines = [score_lines(l, h, w)['leading_lines_score'] for l in e.leading_lines(bgr_dev)]
+        finally:
+            e.dev_free(d_rgb)
+            e.dev_free(d_bgr)
         tags = None
         if self.tagger is not None and self.tagger.text_embeddings is not None and mask & 2:
             tags = self.tagger.get_tags_batch(rec[:, 21:789], self.engine, self.tag_threshold, self.max_tags)
-        if leading_lines is None and self.detect_lines:      # CompositionAnalyzer.detect_leading_lines (multi_pass.py:702-705), batched
-            from .composition import score_lines
-            leading_lines = [score_lines(l, h, w)['leading_lines_score'] for l in self.engine.leading_lines(bgr)]
         out = []
         for i in range(n):
             t = tech[i]

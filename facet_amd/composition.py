@@ -18,15 +18,15 @@ def score_lines(lines, h, w):
     """lines: int32 [k,4] as cv2.HoughLinesP returns them (k may be 0 = the reference's `lines is None`)."""
     if lines is None or len(lines) == 0:
         return {'leading_lines_score': 0, 'line_count': 0}
-    total_score, valid_lines = 0, 0
-    for x1, y1, x2, y2 in np.asarray(lines, dtype=np.int32):
-        length = np.sqrt((x2 - x1) ** 2 + (y2 - y1) ** 2)
-        angle = abs(np.degrees(np.arctan((y2 - y1) / (x2 - x1)))) if x2 - x1 != 0 else 90
-        bonus = 1.5 if 15 <= angle <= 75 else 1.0                     # diagonals guide the eye (:244-247)
-        diagonal = np.sqrt(h ** 2 + w ** 2)
-        total_score += (length / diagonal) * 10 * bonus
-        valid_lines += 1
-    score = min(10.0, total_score / max(1, valid_lines) * 2)
+    seg = np.asarray(lines, dtype=np.int32).reshape(-1, 4)
+    dx, dy = seg[:, 2] - seg[:, 0], seg[:, 3] - seg[:, 1]                # int32, as the reference's per-segment scalars
+    length = np.sqrt(dx ** 2 + dy ** 2)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        angle = np.where(dx != 0, np.abs(np.degrees(np.arctan(dy / dx))), 90.0)
+    bonus = np.where((angle >= 15) & (angle <= 75), 1.5, 1.0)           # diagonals guide the eye (:244-247)
+    terms = (length / np.sqrt(h ** 2 + w ** 2)) * 10 * bonus
+    total_score = np.float64(sum(terms.tolist()))                       # left-to-right float64 sum, like the reference's loop
+    score = min(10.0, total_score / max(1, len(seg)) * 2)
     return {'leading_lines_score': round(score, 2), 'line_count': len(lines)}
 
 

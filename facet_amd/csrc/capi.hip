@@ -1543,6 +1543,24 @@ int fe_roi_laplacian(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int o
   FE_API_END(ctx)
 }
 
+/* RGB <-> BGR copy of a packed uint8 batch into device memory */
+int fe_swap_rb_u8(fe_ctx* ctx, const uint8_t* src, int on_device, size_t pixels, uint8_t* dst_device) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(src && dst_device && pixels > 0, "bad arguments");
+  if (on_device) {
+    FE_CHECK(src != dst_device, "swap_rb: in-place is not supported");
+    launch_swap_rb_u8(src, dst_device, pixels, C.stream);
+  } else {                                   // stage through the destination: upload, then swap each pixel's ends in a second buffer-free pass
+    C.arena.reset();
+    uint8_t* tmp = (uint8_t*)C.arena.alloc(pixels * 3);
+    FE_HIP(hipMemcpyAsync(tmp, src, pixels * 3, hipMemcpyHostToDevice, C.stream));
+    launch_swap_rb_u8(tmp, dst_device, pixels, C.stream);
+  }
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
 /* Leading lines (reference analyzers/composition.py:191-261): blur + Canny map on the GPU, hysteresis + probabilistic Hough per image on host threads */
 int fe_leading_lines(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, int canny_low, int canny_high, int threshold,
                      int min_line_length, int max_line_gap, int max_lines, int* lines, int* counts, uint8_t* edges_out) {

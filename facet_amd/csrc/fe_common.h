@@ -236,6 +236,7 @@ void launch_cv_resize_linear(const uint8_t* src, int n, int h, int w, uint8_t* d
                              const short* ialpha, const int* yofs, const short* ibeta, int area2, hipStream_t s);
 void launch_warp_affine(const uint8_t* src, int h, int w, const int* img_of, const double* Minv, int m, int S, const short* wtab,
                         uint8_t* dst, hipStream_t s);
+void launch_swap_rb_u8(const uint8_t* src, uint8_t* dst, size_t pixels, hipStream_t s);
 void launch_u8_blob(const uint8_t* src, float* dst, size_t pixels, float mean, float scale, int swap_rb, hipStream_t s);
 void launch_scrfd_decode(const float* scores, const float* bbox, const float* kps, int n, int fh, int fw, int A, int K, int stride,
                          float thresh, float det_scale, int level, float* cand, int* counts, int max_cand, hipStream_t s);

@@ -545,4 +545,38 @@ void launch_softmax_rows(float* x, int ld, int rows, int d, hipStream_t s) {
   FE_HIP(hipGetLastError());
 }
 
+// RGB <-> BGR of a packed uint8 image batch (the reference keeps a PIL RGB and a cv2 BGR copy of every image,
+// processing/batch_processor.py:200-215; here the second one is made on the device from the resident first one).
+// Four pixels = three aligned 32-bit words per thread.
+__global__ void swap_rb_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t pixels) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // group of 4 pixels
+  const size_t p0 = q * 4;
+  if (p0 >= pixels) return;
+  if (p0 + 4 <= pixels && ((((uintptr_t)src) | ((uintptr_t)dst)) & 3) == 0) {
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src) + q * 3;
+    const uint32_t a = s4[0], b = s4[1], c = s4[2];
+    uint8_t v[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (a >> (8 * k)) & 255; v[4 + k] = (b >> (8 * k)) & 255; v[8 + k] = (c >> (8 * k)) & 255; }
+    auto pack = [&](int i0, int i1, int i2, int i3) { return (uint32_t)v[i0] | ((uint32_t)v[i1] << 8) | ((uint32_t)v[i2] << 16) | ((uint32_t)v[i3] << 24); };
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(dst) + q * 3;
+    d4[0] = pack(2, 1, 0, 5);
+    d4[1] = pack(4, 3, 8, 7);
+    d4[2] = pack(6, 11, 10, 9);
+  } else {
+    for (size_t p = p0; p < pixels && p < p0 + 4; ++p) {
+      const uint8_t r = src[p * 3], g = src[p * 3 + 1], b = src[p * 3 + 2];
+      dst[p * 3] = b; dst[p * 3 + 1] = g; dst[p * 3 + 2] = r;
+    }
+  }
+}
+
+void launch_swap_rb_u8(const uint8_t* src, uint8_t* dst, size_t pixels, hipStream_t s) {
+  if (!pixels) return;
+  const size_t groups = (pixels + 3) / 4;
+  FE_CHECK(groups < (1ull << 31) * 256, "swap_rb: too many pixels");
+  hipLaunchKernelGGL(swap_rb_u8_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, src, dst, pixels);
+  FE_HIP(hipGetLastError());
+}
+
 }  // namespace fe

@@ -325,16 +325,25 @@ class FaceAnalyzer:
             return self._zeros()
         return self._post(self.face_app.get(img_cv), img_cv)
 
-    def analyze_faces_batch(self, images):
-        """Same-sized BGR images -> list of analyze_faces dicts, with every network run once per batch."""
+    def analyze_faces_batch(self, images, resident=None):
+        """Same-sized BGR images -> list of analyze_faces dicts, with every network run once per batch. resident: optional
+        (device_ptr, n, h, w) of the same BGR batch already in device memory - then `images` (any per-image array-likes, e.g.
+        reversed-channel views of an RGB batch) are only read for the thumbnails of the faces found."""
         if not self.available or images is None or len(images) == 0:
             return [self._zeros() for _ in (images if images is not None else [])]
-        arr = np.ascontiguousarray(np.stack([np.asarray(im) for im in images]), dtype=np.uint8)
         e = self.face_app.engine
-        d = e.dev_alloc(arr.nbytes)
+        if resident is None:
+            arr = np.ascontiguousarray(np.stack([np.asarray(im) for im in images]), dtype=np.uint8)
+            d = e.dev_alloc(arr.nbytes)
+        else:
+            arr, d = images, None
+            assert resident[1] == len(images)
         try:
-            e.h2d(d, arr)
-            dev = (d, arr.shape[0], arr.shape[1], arr.shape[2])
+            if resident is None:
+                e.h2d(d, arr)
+                dev = (d, arr.shape[0], arr.shape[1], arr.shape[2])
+            else:
+                dev = resident
             per_image = self.face_app.get_batch(dev)
             # first pass only records which ROIs the reference logic looks at; one engine call scans them all
             wanted = []
@@ -347,7 +356,8 @@ class FaceAnalyzer:
                     mean = ls / cnt
                     table[r] = (lss / cnt - mean * mean, gs / cnt)
         finally:
-            e.dev_free(d)
+            if d is not None:
+                e.dev_free(d)
         return [self._post(faces, arr[i], lambda x1, y1, x2, y2, i=i: table[(i, x1, y1, x2, y2)]) for i, faces in enumerate(per_image)]
 
     @staticmethod

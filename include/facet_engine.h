@@ -243,6 +243,11 @@ int fe_image_stats(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_
 int fe_roi_laplacian(fe_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int on_device, int m, const int* img_index, const int* rois,
                      double* out);
 
+/* The reference holds every image twice, as PIL RGB and as cv2 BGR (processing/batch_processor.py:200-215). With a resident batch
+ * the second copy is made on the device: dst_device [pixels][3] = src [pixels][3] with the first and third byte of every pixel
+ * exchanged. src: host (on_device = 0) or device memory; not in place. */
+int fe_swap_rb_u8(fe_ctx* ctx, const uint8_t* src, int on_device, size_t pixels, uint8_t* dst_device);
+
 /* Leading lines (last item): the reference's CompositionAnalyzer.detect_leading_lines (analyzers/composition.py:191-261)
  * runs cv2.GaussianBlur(gray, (5,5), 0), cv2.Canny(blurred, 50, 150) and cv2.HoughLinesP(edges, 1, pi/180, 80, minLineLength =
  * int(min(h,w)*0.15), maxLineGap = 20) per image on the CPU. Here the pixel scans (gray, 5x5 fixed-point blur, Sobel, L1 magnitude,

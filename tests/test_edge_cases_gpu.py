@@ -143,3 +143,24 @@ def test_image_stats_degenerate_shapes(engine, shape):
         assert st[i, 256] == lap.sum() and st[i, 257] == (lap * lap).sum()
         assert st[i, 258] == np.abs(R.filter2d_immerkaer(c.gray.astype(np.float64))).sum()
         assert st[i, :256].sum() == shape[0] * shape[1]
+
+
+def test_swap_rb_on_device_and_from_host():
+    """fe_swap_rb_u8: the device-side BGR copy of an RGB batch (any pixel count, host or resident source)."""
+    from facet_amd import Engine
+    e = Engine(0, arena_bytes=1 << 30)
+    rng = np.random.default_rng(0)
+    for npx in (1, 3, 4, 5, 1023, 64 * 77):
+        a = rng.integers(0, 256, (npx, 3), dtype=np.uint8)
+        d_src, d_dst = e.dev_alloc(a.nbytes), e.dev_alloc(a.nbytes)
+        e.h2d(d_src, a)
+        out = np.empty_like(a)
+        e.swap_rb(d_src, npx, d_dst)
+        e.d2h(out, d_dst)
+        assert np.array_equal(out, a[:, ::-1])
+        e.swap_rb(a, npx, d_dst)
+        e.d2h(out, d_dst)
+        assert np.array_equal(out, a[:, ::-1])
+        e.dev_free(d_src)
+        e.dev_free(d_dst)
+    e.close()
