@@ -3,6 +3,7 @@
 #include <thread>
 
 #include "engine.h"
+#include "lines_host.h"
 #include "onnx_graph.h"
 #include <algorithm>
 #include <cmath>

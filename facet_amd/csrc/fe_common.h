@@ -253,11 +253,8 @@ void launch_image_stats(const uint8_t* bgr, int n, int h, int w, uint8_t* gray, 
 void cv_hsv_tables(std::vector<int>& sdiv, std::vector<int>& hdiv);
 // rois: device int [m][4] = x1,y1,x2,y2 (already clipped to the image, x2/y2 exclusive); out: device double [m][4]
 void launch_roi_laplacian(const uint8_t* bgr, int h, int w, const int* img_of, const int* rois, int m, double* out, hipStream_t s);
-// kernels_lines.hip: Gaussian 5x5 + Canny non-maximum-suppression map on the GPU; hysteresis + probabilistic Hough on host threads
+// kernels_lines.hip: Gaussian 5x5 + Canny non-maximum-suppression map on the GPU (host stage: lines_host.h)
 void launch_canny_map(const uint8_t* d_bgr, int n, int h, int w, int low, int high, uint8_t* d_blur, void* d_grad, void* d_mag, uint8_t* d_map,
                       hipStream_t s);
-void canny_hysteresis(uint8_t* map, int h, int w);
-int hough_lines_p(const uint8_t* edges, int h, int w, int threshold, int min_len, int max_gap, int max_lines, int* lines);
-void lines_host_stage(uint8_t* maps, int n, int h, int w, int threshold, int min_len, int max_gap, int max_lines, int* lines, int* counts, int threads);
 
 }  // namespace fe
