@@ -2,6 +2,7 @@
 // gfx950 (MI355X) only. No torch types anywhere in this library.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "fe_check.h"
 #include <cstdint>
 #include <cstdio>
 #include <atomic>
@@ -14,9 +15,6 @@
 
 namespace fe {
 
-struct Error : std::runtime_error {
-  using std::runtime_error::runtime_error;
-};
 
 #define FE_HIP(expr)                                                                      \
   do {                                                                                    \
@@ -39,17 +37,6 @@ inline void ensure_dynamic_lds(const void* kernel, size_t bytes, std::atomic<uin
   FE_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   done.fetch_or(bit, std::memory_order_release);
 }
-
-#define FE_CHECK(cond, ...)                                                               \
-  do {                                                                                    \
-    if (!(cond)) {                                                                        \
-      char _b[512];                                                                       \
-      int _n = snprintf(_b, sizeof _b, "%s:%d: check failed (%s): ", __FILE__, __LINE__,  \
-                        #cond);                                                           \
-      snprintf(_b + _n, sizeof _b - _n, __VA_ARGS__);                                     \
-      throw fe::Error(_b);                                                                \
-    }                                                                                     \
-  } while (0)
 
 // Activation codes shared by the GEMM/conv epilogue.
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_PRELU = 4 };  // PRELU: per-channel slope
