@@ -122,6 +122,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
+    # the host driver of this pool only supports dmabuf IPC: RCCL needs this before the first HIP call (it is exported on the
+    # GPU boxes already; set here too so a bare environment cannot break the N>1 run)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     # Rehearsal knobs (not used by the driver): FACET_BENCH_BACKEND=gloo + FACET_BENCH_DEVICE=0 let two ranks share one
