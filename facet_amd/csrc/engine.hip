@@ -271,6 +271,49 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
       return;
     }
   }
+  // Split-K for few-row, long-K products (ArcFace's 25088 -> 512 embedding layer on a handful of faces): a single tile row would walk K
+  // serially on Cout/64 CUs. K is cut into equal slices that run as ONE batched launch into [splits][M][Cout] partials, which
+  // splitk_reduce sums in a fixed order and finishes with the epilogue.
+  static const bool no_splitk = getenv("FE_NO_SPLITK") != nullptr;
+  if (!no_splitk && w.KH == 1 && w.KW == 1 && o.sh == 1 && o.sw == 1 && o.ph == 0 && o.pw == 0 && !o.gate && p.variant == 0 && p.M <= 256 &&
+      w.CinPad >= 4096 && w.K == w.CinPad && (size_t)((p.M + 127) / 128) * ((w.Cout + 63) / 64) < 64 &&
+      (o.act == ACT_NONE || o.act == ACT_RELU || o.act == ACT_PRELU)) {
+    int splits = 0;
+    for (int s = 64; s >= 2; --s)
+      if (w.CinPad % s == 0 && (w.CinPad / s) % 32 == 0 && w.CinPad / s >= 256) { splits = s; break; }
+    const size_t part_bytes = (size_t)splits * p.M * w.Cout * sizeof(float);
+    if (splits && c.arena.mark() + part_bytes + 1024 <= c.arena.capacity()) {
+      const size_t mark = c.arena.mark();
+      float* part = (float*)c.arena.alloc(part_bytes);
+      const int Ks = w.CinPad / splits;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (c.profile) {
+        FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
+        FE_HIP(hipEventRecord(e0, c.stream));
+      }
+      ConvParams g{};
+      g.x = x.p; g.ldx = x.ld; g.w = w.w; g.ldw = w.Kp; g.y = part; g.ldy = w.Cout;
+      g.M = p.M; g.K = Ks; g.Kp = Ks; g.Cin = Ks; g.Cout = w.Cout;
+      g.N = 1; g.H = 1; g.W = g.M; g.Ho = 1; g.Wo = g.M; g.KH = g.KW = 1; g.sh = g.sw = g.dh = g.dw = 1;
+      g.batch = splits; g.nb1 = 1; g.xs2 = Ks; g.ws2 = Ks; g.ys2 = (long long)p.M * w.Cout;
+      launch_conv(g, c.stream);
+      launch_splitk_reduce(part, splits, p.M, w.Cout, w.scale, w.shift, w.slope, o.act, o.res ? o.res->p : nullptr, o.res ? o.res->ld : 0,
+                           o.res_after_act, y.p, y.ld, c.stream);
+      if (c.profile) {
+        FE_HIP(hipEventRecord(e1, c.stream));
+        FE_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        FE_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        char nm[128];
+        snprintf(nm, sizeof nm, "splitk%d 1x1 M=%d K=%d N=%d", splits, p.M, p.K, p.Cout);
+        c.timings.push_back({nm, 2.0 * p.M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : p.Cout), 0.0, ms});
+      }
+      c.arena.rewind(mark);
+      c.flops_accum += 2.0 * p.M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : p.Cout);
+      return;
+    }
+  }
   // dedicated stem kernel (patch + weights resident in LDS) for 7x7/2 and 3x3/1|2 first layers; falls back otherwise
   static const bool no_stem = getenv("FE_NO_STEM") != nullptr;
   const bool stem = w.wstem && !no_stem && p.variant == 0 && o.sh == o.sw && o.ph == w.KH / 2 && o.pw == w.KW / 2 && o.dh == 1 && o.dw == 1 && !o.res &&

@@ -178,6 +178,8 @@ void launch_maxpool(const Tensor& x, const Tensor& y, int k, int stride, int pad
 void launch_bilinear(const Tensor& x, const Tensor& y, hipStream_t s);
 // adaptive average pool NHWC -> NHWC (torch semantics: start=floor(i*H/Ho), end=ceil((i+1)*H/Ho))
 void launch_adaptive_avgpool(const Tensor& x, const Tensor& y, hipStream_t s);
+void launch_splitk_reduce(const float* part, int splits, int M, int N, const float* scale, const float* shift, const float* slope, int act,
+                          const float* res, int ldr, int res_after_act, float* y, int ldy, hipStream_t s);
 // y = act(x) elementwise / y = x + r
 // y[n,oh,ow,co] = act(scale*sum_tap z[n, oh-ph+kh*dh, ow-pw+kw*dw, tap*Cout+co] + shift)  (stride 1)
 void launch_tap_gather(const float* z, int ldz, int n, int h, int w, int kh, int kw, int ph, int pw, int dh, int dw,

@@ -545,6 +545,33 @@ void launch_softmax_rows(float* x, int ld, int rows, int d, hipStream_t s) {
   FE_HIP(hipGetLastError());
 }
 
+// Sum of split-K partial products + the convolution epilogue: part [splits][M][N] (dense) -> y [M][ldy].
+// Fixed summation order (split 0, 1, 2, ...), so results do not depend on scheduling. act: ACT_NONE / ACT_RELU / ACT_PRELU.
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, const float* __restrict__ slope, int act, const float* __restrict__ res,
+                                     int ldr, int res_after_act, float* __restrict__ y, int ldy) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * N) return;
+  const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+  float acc = 0.f;
+  for (int s = 0; s < splits; ++s) acc += part[(size_t)s * M * N + i];
+  float v = acc * (scale ? scale[n] : 1.f) + (shift ? shift[n] : 0.f);
+  if (res && !res_after_act) v += res[(size_t)m * ldr + n];
+  if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+  else if (act == ACT_PRELU) v = v > 0.f ? v : v * slope[n];
+  if (res && res_after_act) v += res[(size_t)m * ldr + n];
+  y[(size_t)m * ldy + n] = v;
+}
+
+void launch_splitk_reduce(const float* part, int splits, int M, int N, const float* scale, const float* shift, const float* slope, int act,
+                          const float* res, int ldr, int res_after_act, float* y, int ldy, hipStream_t s) {
+  FE_CHECK(act == ACT_NONE || act == ACT_RELU || (act == ACT_PRELU && slope), "splitk_reduce: unsupported activation %d", act);
+  const size_t total = (size_t)M * N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, splits, M, N, scale, shift, slope, act, res,
+                     ldr, res_after_act, y, ldy);
+  FE_HIP(hipGetLastError());
+}
+
 // RGB <-> BGR of a packed uint8 image batch (the reference keeps a PIL RGB and a cv2 BGR copy of every image,
 // processing/batch_processor.py:200-215; here the second one is made on the device from the resident first one).
 // Four pixels = three aligned 32-bit words per thread.

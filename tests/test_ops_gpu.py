@@ -189,3 +189,25 @@ def test_winograd_with_residual(engine, res_after):
     y = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(sh), padding=1)
     ref = (F.relu(y) + torch.from_numpy(r)) if res_after else F.relu(y + torch.from_numpy(r))
     assert np.abs(got - ref.numpy()).max() <= 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("m,cin,cout,act,res", [(8, 25088, 512, None, False), (3, 4096, 96, "relu", True), (130, 8192, 64, None, False),
+                                                (1, 6144, 1000, "relu", False)])
+def test_split_k_long_contraction(engine, m, cin, cout, act, res):
+    """Few rows x long K (ArcFace's 25088 -> 512 embedding layer): K is cut into slices run as one batched launch and summed in a
+    fixed order (engine.hip conv_forward). Checked against float64, with scale / shift / residual / ReLU in the reduce pass."""
+    rng = np.random.default_rng(cin + m)
+    x = rng.standard_normal((m, cin, 1, 1)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    r = rng.standard_normal((m, cout, 1, 1)).astype(np.float32) if res else None
+    got = engine.conv2d(x, w, scale=sc, shift=sh, res=r, act=act)
+    ref = (x[:, :, 0, 0].astype(np.float64) @ w[:, :, 0, 0].astype(np.float64).T) * sc + sh
+    if res:
+        ref = ref + r[:, :, 0, 0]
+    if act == "relu":
+        ref = np.maximum(ref, 0)
+    assert got.shape == (m, cout, 1, 1) and np.abs(got[:, :, 0, 0] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    a = engine.conv2d(x, w, scale=sc, shift=sh, res=r, act=act)
+    assert np.array_equal(a, got)                          # fixed summation order: run-to-run identical
