@@ -143,6 +143,23 @@ class BatchScorer:
                 r['aggregate'], r['category'] = s, c
         return out
 
+    def process_images(self, images_rgb, exif=None, leading_lines=None):
+        """Images of ANY sizes (a list of uint8 [h,w,3] arrays / PIL images, as a chunk of the reference's loader holds them): grouped by
+        shape, each group goes through process_batch as one resident batch; results come back in input order."""
+        arrs = [np.asarray(im.convert('RGB') if hasattr(im, 'convert') else im, dtype=np.uint8) for im in images_rgb]
+        groups = {}
+        for i, a in enumerate(arrs):
+            if a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError(f"image {i}: expected [h,w,3], got {a.shape}")
+            groups.setdefault(a.shape, []).append(i)
+        out = [None] * len(arrs)
+        for idx in groups.values():
+            res = self.process_batch(np.stack([arrs[i] for i in idx]), exif=[exif[i] for i in idx] if exif else None,
+                                     leading_lines=[leading_lines[i] for i in idx] if leading_lines is not None else None)
+            for i, r in zip(idx, res):
+                out[i] = r
+        return out
+
     @staticmethod
     def metrics_multi_pass(res, exif=None):
         """The `metrics` mapping of the multi-pass path (multi_pass.py:713-752) from a process_batch dict."""

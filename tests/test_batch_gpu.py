@@ -67,6 +67,16 @@ def test_process_batch_equals_per_model_calls():
     for r, r2, x in zip(out, out2, exif):
         assert (r2['aggregate'], r2['category']) == aggregate(BatchScorer.metrics_multi_pass(r2, x), pol)
         assert 0.0 <= r2['aggregate'] <= 10.0 and all(r2[k] == r[k] for k in ('aesthetic', 'quality_score', 'comp_score', 'tags', 'face_count', 'tech_sharpness', 'noise_sigma', 'clip_embedding'))
+    # ragged input (real photo chunks mix portrait / landscape sizes): grouped by shape, results in input order
+    mixed = [imgs[0], synthetic_images(8, 1, 160, 224)[0], imgs[1], synthetic_images(9, 1, 224, 160)[0], imgs[2]]
+    bsr = BatchScorer(e, tagger=tg, face_analyzer=fa, tag_threshold=-1.0, max_tags=2, policy=pol)
+    rag = bsr.process_images(mixed, exif=[exif[0]] * 5, leading_lines=[0, 9, 1, 9, 2])
+    assert [(r['image_height'], r['image_width']) for r in rag] == [(224, 256), (160, 224), (224, 256), (224, 160), (224, 256)]
+    for k, j in ((0, 0), (2, 1), (4, 2)):
+        assert rag[k]['quality_score'] == pytest.approx(out2[j]['quality_score'], rel=1e-5) and rag[k]['raw_sharpness_variance'] == out2[j]['raw_sharpness_variance']
+        assert rag[k]['category'] == out2[j]['category'] and rag[k]['aggregate'] == pytest.approx(out2[j]['aggregate'], abs=2e-2)
+    alone = bsr.process_batch(mixed[1][None], exif=[exif[0]], leading_lines=[9])[0]
+    assert rag[1]['quality_score'] == pytest.approx(alone['quality_score'], rel=1e-5) and rag[1]['histogram_data'] == alone['histogram_data']
     # the format invariants the reference's only runtime self-check holds rows to (validation/database_validator.py:14-36, 89-116,
     # 143+, 332-378, 400-425); composition patterns are the 8 names samp_net.py:23-32 emits (the validator's list differs)
     for r in out2:
