@@ -68,3 +68,15 @@ def test_plain_c_program_links_and_runs(tmp_path):
     out = subprocess.run([exe, str(model)], check=True, capture_output=True, text=True, timeout=120).stdout
     assert "facet_amd" in out and "73 nodes" in out and "input [1,3,192,192]" in out
     assert ("no engine context" in out) or ("fe_topiq_score -> " in out)      # CPU box / GPU box without weights
+
+
+def test_every_exported_symbol_is_mapped_in_integration_md():
+    """INTEGRATION.md §4 names, for each entry point of include/facet_engine.h, the reference call it stands behind."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "facet_engine.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    syms = sorted(set(re.findall(r"\b(fe_[a-z0-9_]+)\s*\(", header)))
+    families = [p[:-1] for p in re.findall(r"`(fe_[a-z0-9_]+_\*)`", doc)]          # e.g. `fe_timer_*`
+    missing = [s for s in syms if s not in doc and not any(s.startswith(f) for f in families)]
+    assert len(syms) >= 50 and not missing, missing
