@@ -42,13 +42,13 @@ struct MwcRng {               // OpenCV's generator: multiply-with-carry, seeded
   unsigned next() { state = (uint64_t)(unsigned)state * 4164903690u + (unsigned)(state >> 32); return (unsigned)state; }
   int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
 };
-inline int round_half_even(float v) { return (int)std::nearbyintf(v); }   // default rounding mode = to nearest even
-// rho bin of pixel (x, y) for angle n: two rounded float products and one rounded float sum (never a fused multiply-add)
-inline int rho_bin(const float* trig, int n, int x, int y, int half) {
+inline int round_half_even(float v) { return (int)lrintf(v); }   // default rounding mode = to nearest even; one cvtss2si on x86-64
+// rho bins of pixel (x, y): two rounded float products and one rounded float sum per angle (never a fused multiply-add);
+// the 180 bins of one pixel at once (a straight loop the compiler turns into cvtps2dq lanes)
+inline void rho_bins(const float* cos_t, const float* sin_t, int numangle, int x, int y, int half, int* out) {
 #pragma clang fp contract(off)
-  const float a = (float)x * trig[2 * n];
-  const float b = (float)y * trig[2 * n + 1];
-  return round_half_even(a + b) + half;
+  const float fx = (float)x, fy = (float)y;
+  for (int n = 0; n < numangle; ++n) out[n] = (int)lrintf(fx * cos_t[n] + fy * sin_t[n]) + half;
 }
 }  // namespace
 
@@ -75,7 +75,9 @@ int hough_lines_p(const uint8_t* edges, int h, int w, int threshold, int min_len
   MwcRng rng;
   int found = 0;
   const int shift = 16, half = (numrho - 1) / 2;
-  auto rho_of = [&](int n, int x, int y) { return rho_bin(trig.data(), n, x, y, half); };
+  std::vector<float> cos_t(numangle), sin_t(numangle);      // planar copies for the vector loop
+  for (int n = 0; n < numangle; ++n) { cos_t[n] = trig[2 * n]; sin_t[n] = trig[2 * n + 1]; }
+  std::vector<int> bins(numangle);
   for (int count = (int)nz.size(); count > 0; --count) {
     const int idx = rng.uniform(0, count);
     const int pt = nz[idx];
@@ -83,8 +85,9 @@ int hough_lines_p(const uint8_t* edges, int h, int w, int threshold, int min_len
     const int i = pt / w, j = pt - i * w;
     if (!mask[pt]) continue;                                 // already part of an extracted segment
     int max_val = threshold - 1, max_n = 0;
+    rho_bins(cos_t.data(), sin_t.data(), numangle, j, i, half, bins.data());
     for (int n = 0; n < numangle; ++n) {
-      const int val = ++accum[(size_t)n * numrho + rho_of(n, j, i)];
+      const int val = ++accum[(size_t)n * numrho + bins[n]];
       if (max_val < val) { max_val = val; max_n = n; }
     }
     if (max_val < threshold) continue;
@@ -122,8 +125,10 @@ int hough_lines_p(const uint8_t* edges, int h, int w, int threshold, int min_len
         const int j1 = xflag ? x : x >> shift, i1 = xflag ? y >> shift : y;
         uint8_t& m = mask[(size_t)i1 * w + j1];
         if (m) {
-          if (good)
-            for (int n = 0; n < numangle; ++n) --accum[(size_t)n * numrho + rho_of(n, j1, i1)];
+          if (good) {
+            rho_bins(cos_t.data(), sin_t.data(), numangle, j1, i1, half, bins.data());
+            for (int n = 0; n < numangle; ++n) --accum[(size_t)n * numrho + bins[n]];
+          }
           m = 0;
         }
         if (i1 == end_y[k] && j1 == end_x[k]) break;
