@@ -8,7 +8,7 @@
 //     lanes 0-31 feed tap 2p, lanes 32-63 tap 2p+1 of a tap pair); the zero 4th channel is skipped -> 3 MFMAs per tap pair,
 //     K_eff = 150 for 147 algorithmic,
 //   * operands are swapped (weights as A, pixels as B) so every lane ends up holding 4 consecutive output channels of ITS
-//     pixel: the epilogue stores float4 rows directly from the accumulators, no LDS transpose.
+//     pixel: the epilogue moves float4 groups (no scalar shuffles) through a wave-private LDS transpose to full-row stores.
 #include "fe_common.h"
 
 namespace fe {
@@ -86,36 +86,45 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemParams p) {
       }
   }
 
-  // ---- epilogue: D[row = cout][col = pixel]; lane (r, h) holds couts (e&3) + 8(e>>2) + 4h of pixel r --------------------
+  // ---- epilogue: D[row = cout][col = pixel]; lane (r, h) holds couts (e&3) + 8(e>>2) + 4h of pixel r. Each wave transposes its
+  // 64 pixels x Cout tile through LDS (the patch / weight area is free now) so that 16 (8) lanes write one pixel's whole 256-B
+  // (128-B) channel row and a wave stores 1 KiB contiguous runs - the direct form stored 32-byte pieces of 64 different rows.
+  __syncthreads();
+  constexpr int CO = TN * 32, ES = CO + 4, LPP = CO / 4;         // floats per pixel row in LDS (padded), lanes per pixel
+  float* E = smem + (size_t)wave * 64 * ES;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int oy = oy0 + 2 * wave + i, ox = ox0 + r;
-    if (oy >= p.Ho || ox >= p.Wo) continue;
-    float* dst = p.y + (((size_t)img * p.Ho + oy) * p.Wo + ox) * p.ldy;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = j * 32 + 8 * g + 4 * h;
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + co);
-        if (p.shift) sf = *reinterpret_cast<const float4*>(p.shift + co);
-        float4 v = make_float4(acc[j][i][4 * g] * sc.x + sf.x, acc[j][i][4 * g + 1] * sc.y + sf.y, acc[j][i][4 * g + 2] * sc.z + sf.z,
-                               acc[j][i][4 * g + 3] * sc.w + sf.w);
-        if (p.act == 1) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
-        else if (p.act == 2) {
-          const float4 sl = *reinterpret_cast<const float4*>(p.slope + co);
-          v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y; v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
-        }
-        *reinterpret_cast<float4*>(dst + co) = v;
-      }
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(E + (size_t)(i * 32 + r) * ES + j * 32 + 8 * g + 4 * h) =
+            make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+  // wave-private region: the wave's own LDS writes are complete before its reads (same wave, lgkmcnt) - no block barrier needed
+  const int c4 = (lane % LPP) * 4;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f), sl = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + c4);
+  if (p.shift) sf = *reinterpret_cast<const float4*>(p.shift + c4);
+  if (p.act == 2) sl = *reinterpret_cast<const float4*>(p.slope + c4);
+  constexpr int PPI = 64 / LPP;                                  // pixels per iteration of the wave
+#pragma unroll
+  for (int it = 0; it < 64 / PPI; ++it) {
+    const int px = it * PPI + lane / LPP;                        // 0..63: row i = px / 32 of the wave's two rows, column px % 32
+    const int oy = oy0 + 2 * wave + (px >> 5), ox = ox0 + (px & 31);
+    float4 v = *reinterpret_cast<const float4*>(E + (size_t)px * ES + c4);
+    v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+    if (p.act == 1) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+    else if (p.act == 2) { v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y; v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w; }
+    if (oy < p.Ho && ox < p.Wo) *reinterpret_cast<float4*>(p.y + (((size_t)img * p.Ho + oy) * p.Wo + ox) * p.ldy + c4) = v;
   }
 }
 
 template <int TN, int K, int S>
 static void launch_stem_t(const StemParams& p, hipStream_t s) {
   constexpr int PH = (STEM_TH - 1) * S + K, PW = (STEM_TW - 1) * S + K, T2 = (K * K + 1) & ~1;
-  constexpr size_t lds = ((size_t)PH * PW * 4 + (size_t)TN * 32 * T2 * 4) * sizeof(float);
+  constexpr size_t main_lds = ((size_t)PH * PW * 4 + (size_t)TN * 32 * T2 * 4) * sizeof(float);
+  constexpr size_t epi_lds = (size_t)4 * 64 * (TN * 32 + 4) * sizeof(float);     // four wave-private transpose regions
+  constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   static std::atomic<uint64_t> lds_set{0};
   ensure_dynamic_lds((const void*)stem_kernel<TN, K, S>, lds, lds_set);
   const dim3 grid((p.Wo + STEM_TW - 1) / STEM_TW, (p.Ho + STEM_TH - 1) / STEM_TH, p.N);
