@@ -63,7 +63,7 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
                     face_ref.landmark_get(fm["lmk"][0], a, det[f, :4], 192, 0.0, 1.0)
                     face_ref.arcface_get(fm["rec"][0], a, kpss[f], 127.5, 127.5)
         extras.append(extra_faces)
-    if workload in ("ensemble", "full"):
+    if workload in ("ensemble", "full", "topiq_clip"):
         from PIL import Image
         from oracle.clip_vit import CLIPImage, aesthetic_head, CLIP_MEAN, CLIP_STD
         from oracle.sampnet import U2NETP, SAMPNet
@@ -77,7 +77,7 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
                                 for p in pils])
             f = clip.encode_image((c_in - cl_m) / cl_s)
             head(f)
-            for p in pils:
+            for p in (pils if workload != "topiq_clip" else []):
                 x = torch.from_numpy(np.asarray(p.resize((224, 224), Image.BILINEAR), np.float32) / 255).permute(2, 0, 1)[None]
                 x = (x - im_m) / im_s
                 sn(x, u2(x))
@@ -92,7 +92,7 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
         for ex in extras:
             ex(imgs)
         dt = time.perf_counter() - t0
-    what = {"topiq": "oracle/topiq.py CFANet", "ensemble": "oracle TOPIQ + CLIP ViT-L/14 + aesthetic MLP + U2NETP + SAMPNet",
+    what = {"topiq": "oracle/topiq.py CFANet", "topiq_clip": "oracle TOPIQ + CLIP ViT-L/14 + aesthetic MLP", "ensemble": "oracle TOPIQ + CLIP ViT-L/14 + aesthetic MLP + U2NETP + SAMPNet",
             "faces": f"oracle TOPIQ + U2NETP + SAMPNet + face_ref SCRFD@640/landmarks/ArcFace ({FACES_PER_IMAGE} faces/image)",
             "full": f"oracle TOPIQ + CLIP ViT-L/14 + aesthetic MLP + U2NETP + SAMPNet + face_ref SCRFD@640/landmarks/ArcFace "
                     f"({FACES_PER_IMAGE} faces/image)"}[workload]
@@ -109,8 +109,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--microbatch", type=int, default=32)
-    ap.add_argument("--workload", choices=["topiq", "ensemble", "faces", "full"], default="topiq",
-                    help="topiq = BASELINE.json configs[1]; ensemble = TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP; "
+    ap.add_argument("--workload", choices=["topiq", "topiq_clip", "ensemble", "faces", "full"], default="topiq",
+                    help="topiq = BASELINE.json configs[1]; topiq_clip = the 'TOPIQ+CLIP forward' of north_star's roofline target; ensemble = TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP; "
                          "faces = configs[2]: TOPIQ + SAMP-Net + SCRFD/landmarks/ArcFace; full = the metric's whole ensemble "
                          "(TOPIQ + SAMP + CLIP + InsightFace-style faces)")
     ap.add_argument("--cpu-sample", type=int, default=4, help="images for the CPU baseline leg (0 = skip)")
@@ -147,7 +147,7 @@ def main():
     B, HW = args.batch, args.size
     eng = Engine(dev_index, arena_bytes=(4 + 2 * args.microbatch * max(1, (HW * HW) // (1024 * 1024))) << 30)
     eng.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", seed=3))
-    if args.workload in ("ensemble", "full"):
+    if args.workload in ("topiq_clip", "ensemble", "full"):
         eng.load_weights(FE_MODEL_CLIP, synthetic_state_dict("clip", seed=3))
         eng.load_weights(FE_MODEL_AESTHETIC, synthetic_state_dict("aesthetic", seed=3))
     if args.workload in ("ensemble", "faces", "full"):
@@ -182,9 +182,9 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        if args.workload == "ensemble":
-            rec, mask = eng.ensemble_score(images)      # [B, 789] per-image records
-            assert mask == 7
+        if args.workload in ("ensemble", "topiq_clip"):
+            rec, mask = eng.ensemble_score(images)      # [B, 789] per-image records (fields of models not loaded stay 0)
+            assert mask == (7 if args.workload == "ensemble" else 3)
             return gather_scores(rec, world, dev_index)
         if args.workload in ("faces", "full"):
             rec, mask = eng.ensemble_score(images)      # faces: TOPIQ + SAMP fields only (CLIP not loaded)
@@ -258,6 +258,8 @@ def main():
                                    (f"whole ensemble of the metric: TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP + InsightFace-style "
                                     f"SCRFD@640 / 2d106 landmarks / ArcFace-R50 ({FACES_PER_IMAGE} best faces/image, stand-in ONNX graphs) fp32, "
                                     f"batch {B}/GPU, {HW}x{HW}") if args.workload == "full" else
+                                   (f"TOPIQ-NR + CLIP ViT-L/14 image tower + aesthetic MLP fp32 (north_star's 'TOPIQ+CLIP forward'), "
+                                    f"batch {B}/GPU, {HW}x{HW} RGB") if args.workload == "topiq_clip" else
                                    (f"ensemble TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP fp32 (no InsightFace), "
                                     f"batch {B}/GPU, {HW}x{HW} RGB"),
                        "global_batch": B * world, "image_size": HW, "microbatch": args.microbatch,
