@@ -96,9 +96,15 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
             "faces": f"oracle TOPIQ + U2NETP + SAMPNet + face_ref SCRFD@640/landmarks/ArcFace ({FACES_PER_IMAGE} faces/image)",
             "full": f"oracle TOPIQ + CLIP ViT-L/14 + aesthetic MLP + U2NETP + SAMPNet + face_ref SCRFD@640/landmarks/ArcFace "
                     f"({FACES_PER_IMAGE} faces/image)"}[workload]
-    return {"value": round(sample / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+    cpu_model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), cpu_model)
+    except OSError:
+        pass
+    return {"value": round(sample / dt, 4), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
             "sample": f"{sample} x {hw}x{hw} synthetic RGB through {what} (torch {torch.__version__} CPU fp32, {cores} "
-                      "threads; TOPIQ/SAMP one image per forward, CLIP one batch)"}
+                      f"threads on {cpu_model}; TOPIQ/SAMP one image per forward, CLIP one batch)"}
 
 
 def main():
