@@ -18,5 +18,6 @@ Pinning status (see DESIGN.md "Oracle"):
   * ONNX graph evaluation (oracle/onnx_ref.py), face pre/post-processing (oracle/face_ref.py), technical metrics
     (oracle/technical_ref.py), leading lines (oracle/lines_ref.py: Gaussian / Canny / probabilistic Hough): restate ONNX operator semantics / insightface / OpenCV fixed-point arithmetic
     [DEP-KNOWLEDGE]; onnxruntime, insightface, cv2 and the buffalo_l files are absent -> "parity unpinned"; the OpenCV
-    pieces are held to known answers in tests/test_cv_semantics.py and tests/test_lines_host.py.
+    pieces are held to known answers in tests/test_cv_semantics.py and tests/test_lines_host.py; the ONNX evaluator reproduces
+    torch's outputs on models serialised by PyTorch's own exporter (tests/golden/torch_onnx_*.npz).
 """

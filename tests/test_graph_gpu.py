@@ -134,3 +134,30 @@ def test_winograd_inside_graphs_with_padded_channels(engine):
     data = g.build([("x", ["N", 3, 21, 30])], [(e, ["N", 24, 21, 30]), (c, ["N", 150, 21, 30])])
     x = np.random.default_rng(2).uniform(-1, 1, (2, 3, 21, 30)).astype(np.float32)
     _check(engine, data, x)
+
+
+def _torch_exported():
+    import glob
+    import os
+    return sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "torch_onnx_*.npz")))
+
+
+@pytest.mark.parametrize("path", _torch_exported(), ids=lambda p: p.split("torch_onnx_")[-1][:-4])
+def test_graphs_from_torchs_exporter_match_torch(engine, path):
+    """Models serialised by PyTorch's own exporter (not by facet_amd/onnx_writer.py), checked against the outputs TORCH computed
+    (tests/golden/make_torch_onnx_golden.py): IResNet-style blocks with un-fused BatchNormalization / PRelu / Flatten / Gemm /
+    1-D BatchNormalization, an FPN detector with Resize / MaxPool / Transpose / Reshape / Mul-by-scalar heads in opsets 11 and 13,
+    a depthwise-separable landmark net with GlobalAveragePool. Other batch sizes than the exported one run too."""
+    z = np.load(path)
+    blob, x = z["onnx"].tobytes(), z["x"]
+    engine.graph_load(3, blob)
+    got = engine.graph_run(3, x)
+    want = [z[f"y{i}"] for i in range(len(got))]
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        assert float(np.abs(g - w).max()) <= 2e-4 * max(1.0, float(np.abs(w).max())), (path, g.shape, float(np.abs(g - w).max()))
+    if "det" not in path:                     # the detector's Reshape(-1, C) folds the batch into the anchors; the others are per-row
+        xb = np.concatenate([x, x[::-1] * 0.5], 0)
+        gb = engine.graph_run(3, xb)
+        assert gb[0].shape[0] == xb.shape[0] and float(np.abs(gb[0][:x.shape[0]] - got[0]).max()) <= 1e-5 * max(1.0, float(np.abs(got[0]).max()))
+    engine.graph_unload(3)

@@ -140,3 +140,29 @@ def test_reader_under_sanitizers_on_mutated_files(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = out.stdout.splitlines()
     assert len(lines) == 600 and all(l.startswith(("ok ", "error ")) for l in lines) and sum(l.startswith("error") for l in lines) > 100
+
+
+def _torch_exported():
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "torch_onnx_*.npz")))
+    assert len(files) >= 4
+    return files
+
+
+@pytest.mark.parametrize("path", _torch_exported(), ids=lambda p: p.split("torch_onnx_")[-1][:-4])
+def test_files_written_by_torchs_exporter(path):
+    """.onnx bytes from PyTorch's own exporter (tests/golden/make_torch_onnx_golden.py), i.e. an encoder this repo did not write: the
+    engine's reader accepts them and reports what the oracle's reader sees, and the oracle's evaluator reproduces the outputs
+    torch computed for the stored input - which pins the oracle's ONNX operator semantics to torch through a mainstream exporter."""
+    z = np.load(path)
+    blob = z["onnx"].tobytes()
+    m = onnx_ref.parse(blob)
+    p = onnx_probe(blob)
+    assert p["nodes"] == len(m["nodes"]) and p["initializers"] == len(m["init"]) and p["input_dims"] == list(z["x"].shape[:1] + z["x"].shape[1:])
+    outs = onnx_ref.run(m, z["x"])
+    want = [z[f"y{i}"] for i in range(len(outs))]
+    assert f"y{len(outs)}" not in z.files
+    for o, w in zip(outs, want):
+        o = np.asarray(o)
+        assert o.shape == w.shape and float(np.abs(o - w).max()) <= 2e-6 * max(1.0, float(np.abs(w).max()))
