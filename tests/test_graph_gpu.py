@@ -161,3 +161,52 @@ def test_graphs_from_torchs_exporter_match_torch(engine, path):
         gb = engine.graph_run(3, xb)
         assert gb[0].shape[0] == xb.shape[0] and float(np.abs(gb[0][:x.shape[0]] - got[0]).max()) <= 1e-5 * max(1.0, float(np.abs(got[0]).max()))
     engine.graph_unload(3)
+
+
+def test_full_size_iresnet50_exported_by_torch(engine):
+    """The real ArcFace-R50 structure (IResNet-50: 3-4-14-3 blocks, 25088 -> 512 embedding layer, 1-D BatchNormalization), built in
+    torch with seeded weights, serialised on the spot by PyTorch's exporter and run on the engine: embeddings equal torch's.
+    (w600k_r50.onnx itself is such a PyTorch export; the file is not available offline.)"""
+    import importlib.util
+    import io
+    import os
+    import torch
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(__file__), "golden", "make_torch_onnx_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)                                # also installs the exporter bypass for the absent `onnx` package
+    nn = torch.nn
+
+    class IResNet50(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = nn.Sequential(nn.Conv2d(3, 64, 3, 1, 1, bias=False), nn.BatchNorm2d(64), nn.PReLU(64))
+            blocks, cin = [], 64
+            for cout, n in ((64, 3), (128, 4), (256, 14), (512, 3)):
+                for b in range(n):
+                    blocks.append(mk.IBlock(cin, cout, 2 if b == 0 else 1))
+                    cin = cout
+            self.body = nn.Sequential(*blocks)
+            self.bn2, self.fc, self.features = nn.BatchNorm2d(512), nn.Linear(512 * 7 * 7, 512), nn.BatchNorm1d(512)
+
+        def forward(self, x):
+            return self.features(self.fc(torch.flatten(self.bn2(self.body(self.stem(x))), 1)))
+
+    torch.manual_seed(4)
+    g = torch.Generator().manual_seed(5)
+    m = IResNet50().eval()
+    with torch.no_grad():
+        mk.randomise(m, g)
+        x = torch.rand((3, 3, 112, 112), generator=g) * 2 - 1
+        ref = m(x).numpy()
+        f = io.BytesIO()
+        torch.onnx.export(m, (x,), f, dynamo=False, opset_version=11, input_names=["input.1"], output_names=["683"])
+    blob = f.getvalue()
+    assert len(blob) > 150e6                                     # ~43.6 M parameters
+    engine.graph_load(3, blob)
+    info = engine.graph_info(3)
+    (emb,) = engine.graph_run(3, x.numpy())
+    engine.graph_unload(3)
+    assert emb.shape == (3, 512) and np.isfinite(emb).all()
+    assert float(np.abs(emb - ref).max()) <= 1e-3 * max(1.0, float(np.abs(ref).max())), float(np.abs(emb - ref).max())
+    cos = (emb * ref).sum(1) / (np.linalg.norm(emb, axis=1) * np.linalg.norm(ref, axis=1))
+    assert (cos > 0.999999).all() and info is not None
