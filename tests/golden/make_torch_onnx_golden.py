@@ -83,6 +83,26 @@ class DetLike(nn.Module):
         return tuple(scores + boxes + kps)
 
 
+class DetDynamic(DetLike):
+    """The same detector written the way mmdet-style code is: upsampling to the size of the lateral map (`size=x.shape[-2:]`), exported
+    with dynamic batch / height / width - the file then carries Shape / Gather / Unsqueeze / Concat / Slice / Cast chains in front
+    of every Resize, which a runtime has to fold on the host for the actual input size."""
+    def forward(self, x):
+        c8 = self.s8(self.stem(x))
+        c8 = F.relu(c8 + self.r8(c8))
+        c16 = self.s16(c8)
+        c32 = self.s32(c16)
+        p32 = self.lat[2](c32)
+        p16 = self.lat[1](c16) + F.interpolate(p32, size=c16.shape[-2:], mode="nearest")
+        p8 = self.lat[0](c8) + F.interpolate(p16, size=c8.shape[-2:], mode="nearest")
+        outs = []
+        for i, f in enumerate([self.smooth[0](p8), self.smooth[1](p16), self.smooth[2](p32)]):
+            t = self.tower(f)
+            outs.append(self.cls(t).permute(0, 2, 3, 1).reshape(-1, 1).sigmoid())
+            outs.append((self.box(t) * self.scales[i]).permute(0, 2, 3, 1).reshape(-1, 4))
+        return tuple(outs)
+
+
 class LmkLike(nn.Module):
     """MobileNet-style landmark regressor: depthwise-separable blocks with PReLU, global average pooling, FC."""
     def __init__(self):
@@ -114,9 +134,9 @@ def randomise(m, g):
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     cases = [("arc", ArcLike, (2, 3, 64, 64), 11), ("det", DetLike, (1, 3, 64, 96), 11),
-             ("det", DetLike, (1, 3, 64, 96), 13), ("lmk", LmkLike, (2, 3, 48, 48), 11)]
+             ("det", DetLike, (1, 3, 64, 96), 13), ("lmk", LmkLike, (2, 3, 48, 48), 11), ("detdyn", DetDynamic, (1, 3, 64, 96), 11)]
     for name, cls, shape, opset in cases:
-        torch.manual_seed({"arc": 1, "det": 2, "lmk": 3}[name])
+        torch.manual_seed({"arc": 1, "det": 2, "lmk": 3, "detdyn": 2}[name])
         g = torch.Generator().manual_seed(11)
         m = cls().eval()
         with torch.no_grad():
@@ -125,11 +145,16 @@ def main():
             ref = m(x)
             ref = ref if isinstance(ref, tuple) else (ref,)
             f = io.BytesIO()
+            dyn = {"input": {0: "n", 2: "h", 3: "w"}} if name == "detdyn" else None
             torch.onnx.export(m, (x,), f, dynamo=False, opset_version=opset, input_names=["input"],
-                              output_names=[f"out{i}" for i in range(len(ref))])
+                              output_names=[f"out{i}" for i in range(len(ref))], dynamic_axes=dyn)
+            extra = {}
+            if dyn:                                    # a second input of another size through the same file
+                x2 = torch.rand((1, 3, 96, 128), generator=g) * 2 - 1
+                extra = {"x2": x2.numpy(), **{f"z{i}": r.numpy() for i, r in enumerate(m(x2))}}
         blob = np.frombuffer(f.getvalue(), np.uint8)
         path = os.path.join(here, f"torch_onnx_{name}_opset{opset}.npz")
-        np.savez_compressed(path, onnx=blob, x=x.numpy(), **{f"y{i}": r.numpy() for i, r in enumerate(ref)})
+        np.savez_compressed(path, onnx=blob, x=x.numpy(), **{f"y{i}": r.numpy() for i, r in enumerate(ref)}, **extra)
         print(f"{os.path.basename(path)}: model {blob.size} B, file {os.path.getsize(path)} B, outputs {[tuple(r.shape) for r in ref]}")
 
 

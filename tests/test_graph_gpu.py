@@ -146,7 +146,8 @@ def _torch_exported():
 def test_graphs_from_torchs_exporter_match_torch(engine, path):
     """Models serialised by PyTorch's own exporter (not by facet_amd/onnx_writer.py), checked against the outputs TORCH computed
     (tests/golden/make_torch_onnx_golden.py): IResNet-style blocks with un-fused BatchNormalization / PRelu / Flatten / Gemm /
-    1-D BatchNormalization, an FPN detector with Resize / MaxPool / Transpose / Reshape / Mul-by-scalar heads in opsets 11 and 13,
+    1-D BatchNormalization, an FPN detector with Resize / MaxPool / Transpose / Reshape / Mul-by-scalar heads in opsets 11 and 13 (also exported with dynamic
+    axes: Shape / Gather / Unsqueeze / Concat / Slice / Cast chains feeding Resize, run at two input sizes),
     a depthwise-separable landmark net with GlobalAveragePool. Other batch sizes than the exported one run too."""
     z = np.load(path)
     blob, x = z["onnx"].tobytes(), z["x"]
@@ -156,6 +157,11 @@ def test_graphs_from_torchs_exporter_match_torch(engine, path):
     for g, w in zip(got, want):
         assert g.shape == w.shape
         assert float(np.abs(g - w).max()) <= 2e-4 * max(1.0, float(np.abs(w).max())), (path, g.shape, float(np.abs(g - w).max()))
+    if "x2" in z.files:                       # dynamic-shape export: Shape / Gather / Concat / Slice chains folded for another input size
+        got2 = engine.graph_run(3, z["x2"])
+        for i, g in enumerate(got2):
+            w = z[f"z{i}"]
+            assert g.shape == w.shape and float(np.abs(g - w).max()) <= 2e-4 * max(1.0, float(np.abs(w).max())), (i, g.shape)
     if "det" not in path:                     # the detector's Reshape(-1, C) folds the batch into the anchors; the others are per-row
         xb = np.concatenate([x, x[::-1] * 0.5], 0)
         gb = engine.graph_run(3, xb)

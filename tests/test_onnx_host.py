@@ -159,10 +159,14 @@ def test_files_written_by_torchs_exporter(path):
     blob = z["onnx"].tobytes()
     m = onnx_ref.parse(blob)
     p = onnx_probe(blob)
-    assert p["nodes"] == len(m["nodes"]) and p["initializers"] == len(m["init"]) and p["input_dims"] == list(z["x"].shape[:1] + z["x"].shape[1:])
-    outs = onnx_ref.run(m, z["x"])
-    want = [z[f"y{i}"] for i in range(len(outs))]
-    assert f"y{len(outs)}" not in z.files
-    for o, w in zip(outs, want):
-        o = np.asarray(o)
-        assert o.shape == w.shape and float(np.abs(o - w).max()) <= 2e-6 * max(1.0, float(np.abs(w).max()))
+    assert p["nodes"] == len(m["nodes"]) and p["initializers"] == len(m["init"])
+    assert all(d in (-1, s_) for d, s_ in zip(p["input_dims"], z["x"].shape))          # -1 = exported as a dynamic axis
+    for xin, pre in (("x", "y"), ("x2", "z")):                                          # x2: another size through a dynamic-shape file
+        if xin not in z.files:
+            continue
+        outs = onnx_ref.run(m, z[xin])
+        want = [z[f"{pre}{i}"] for i in range(len(outs))]
+        assert f"{pre}{len(outs)}" not in z.files
+        for o, w in zip(outs, want):
+            o = np.asarray(o)
+            assert o.shape == w.shape and float(np.abs(o - w).max()) <= 2e-6 * max(1.0, float(np.abs(w).max()))
