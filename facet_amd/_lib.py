@@ -104,6 +104,7 @@ SIGNATURES = {
     "fe_roi_laplacian": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_double)]),
     "fe_cv_resize_linear_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "fe_aesthetic_score": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]),
     "fe_swap_rb_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "fe_leading_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -405,6 +406,13 @@ class Engine:
         out = np.empty((n, oh, ow, 3), np.uint8)
         self._ck(self.lib.fe_resize_u8(self.h, a.ctypes.data_as(C.c_void_p), n, h, w, oh, ow, FILTERS[filter], 0,
                                        out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def aesthetic_score(self, feats):
+        """feats float32 [n,768] -> raw aesthetic_head outputs [n] (before the (x+1)*5 clamp)."""
+        a = np.ascontiguousarray(feats, dtype=np.float32).reshape(-1, 768)
+        out = np.empty((a.shape[0],), np.float32)
+        self._ck(self.lib.fe_aesthetic_score(self.h, a.ctypes.data_as(_f32p), a.shape[0], out.ctypes.data_as(_f32p)))
         return out
 
     def clip_encode_images(self, images, normalized=True, aesthetic=True):

@@ -104,3 +104,30 @@ class ClipAestheticScorer:
                                                         aesthetic=True)
         return [(max(0.0, min(10.0, (float(aes[i]) + 1) * 5)), emb[i].astype(np.float32).tobytes(), None, 'clip-mlp')
                 for i in range(len(pil_images))]
+
+    # ---- the single-image entry points of the reference's Facet class (processing/scorer.py:587-638) ------------------------------
+    def get_aesthetic_with_embedding(self, image_pil):
+        """(aesthetic score, 3072-byte normalised embedding) - scorer.py:603-617."""
+        score, emb, _, _ = self.get_aesthetic_and_quality_batch([image_pil])[0]
+        return score, emb
+
+    def get_aesthetic_score(self, image_pil):
+        """scorer.py:587-601."""
+        return self.get_aesthetic_with_embedding(image_pil)[0]
+
+    def get_aesthetic_and_quality(self, pil_img):
+        """scorer.py:631-638: (aesthetic, clip_embedding_bytes, None, 'clip-mlp')."""
+        return self.get_aesthetic_and_quality_batch([pil_img])[0]
+
+    def score_from_embedding(self, embedding_bytes):
+        """Recalculate the aesthetic score from a stored 3072-byte embedding (scorer.py:619-629): the stored, L2-normalised vector goes
+        through the same MLP head (the reference does exactly this, although the live path feeds the un-normalised features)."""
+        return self.scores_from_embeddings([embedding_bytes])[0]
+
+    def scores_from_embeddings(self, blobs):
+        """score_from_embedding for many stored embeddings in one engine call (the reference's recalculation loops call it per row)."""
+        vecs = np.stack([np.frombuffer(b, dtype=np.float32) for b in blobs]) if len(blobs) else np.zeros((0, 768), np.float32)
+        if len(vecs) == 0:
+            return []
+        raw = self._engine.aesthetic_score(vecs)
+        return [max(0.0, min(10.0, (float(r) + 1) * 5)) for r in raw]

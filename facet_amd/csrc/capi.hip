@@ -827,6 +827,26 @@ class SampBatcher {
 };
 }  // extern "C++"
 
+/* aesthetic_head on given feature / embedding vectors (reference Facet.score_from_embedding, processing/scorer.py:619-629) */
+int fe_aesthetic_score(fe_ctx* ctx, const float* feats, int n, float* aesthetic_raw) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  if (!C.aesthetic) { C.err = "aesthetic head weights not loaded"; return FE_ERR_NOT_LOADED; }
+  FE_CHECK(feats && aesthetic_raw && n > 0, "bad arguments");
+  const int d = 768;
+  for (int i0 = 0; i0 < n; i0 += 65536) {
+    const int nb = std::min(65536, n - i0);
+    C.arena.reset();
+    float* d_in = (float*)C.arena.alloc((size_t)nb * d * sizeof(float));
+    float* d_out = (float*)C.arena.alloc((size_t)nb * sizeof(float));
+    FE_HIP(hipMemcpyAsync(d_in, feats + (size_t)i0 * d, (size_t)nb * d * sizeof(float), hipMemcpyHostToDevice, C.stream));
+    aesthetic_forward(C, *C.aesthetic, d_in, nb, d_out);
+    FE_HIP(hipMemcpyAsync(aesthetic_raw + i0, d_out, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+    FE_HIP(hipStreamSynchronize(C.stream));
+  }
+  FE_API_END(ctx)
+}
+
 int fe_clip_encode_image(fe_ctx* ctx, const float* x, int n, int on_device, float* features, float* emb_norm,
                          float* aesthetic_raw) {
   FE_API_BEGIN(ctx)

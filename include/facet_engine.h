@@ -131,6 +131,11 @@ int fe_samp_forward(fe_ctx* ctx, const float* x, int n, float* pattern_weights, 
 int fe_clip_encode_image(fe_ctx* ctx, const float* x, int n, int on_device, float* features, float* emb_norm,
                          float* aesthetic_raw);
 
+/* aesthetic_head on vectors already at hand: feats [n,768] -> aesthetic_raw [n]. The reference recomputes scores from STORED
+ * embeddings this way (Facet.score_from_embedding, processing/scorer.py:619-629: the 3072-byte blob, i.e. the L2-normalised
+ * embedding, goes through the same MLP); the (x+1)*5 clamp stays on the host. */
+int fe_aesthetic_score(fe_ctx* ctx, const float* feats, int n, float* aesthetic_raw);
+
 /* ---- preprocessing: PIL-exact uint8 resampling (bit-for-bit PIL.Image.resize, RGB 8-bit) ---------------- */
 enum fe_filter { FE_LANCZOS = 1, FE_BILINEAR = 2, FE_BICUBIC = 3 }; /* PIL.Image.Resampling values */
 /* src [n,h,w,3] uint8 -> dst [n,oh,ow,3] uint8; replaces PIL `image.resize((ow,oh), filter)`

@@ -43,6 +43,18 @@ def test_model_manager_lifecycle_and_scorers(engine):
     assert tuple(f.shape) == (1, 768) and str(next(clip["model"].parameters()).dtype) == "torch.float32"
     _, emb_gpu, _ = engine.clip_encode_images(imgs[:1])   # GPU preprocessing path vs host PIL preprocessing path
     assert float((emb_gpu[0] * emb).sum()) > 1 - 1e-5
+    # single-image entry points of Facet (scorer.py:587-638) and the recalculation from stored embeddings (:619-629)
+    a1, e1 = sc.get_aesthetic_with_embedding(pils[1])
+    assert a1 == pytest.approx(out[1][0], abs=1e-4) and e1 == out[1][1] and sc.get_aesthetic_score(pils[1]) == pytest.approx(a1, abs=1e-6)
+    assert sc.get_aesthetic_and_quality(pils[2])[1:] == (out[2][1], None, "clip-mlp")
+    from facet_amd.weights import synthetic_state_dict
+    sd = synthetic_state_dict("aesthetic", 9)                 # the head ClipAestheticScorer loaded: Linear 768-256, ReLU, Linear 256-1
+    w1, b1, w2, b2 = (sd[k].astype(np.float64) for k in sorted(sd, key=lambda k: (k.split(".")[0], "bias" in k)))
+    for blob, got in zip([o[1] for o in out], sc.scores_from_embeddings([o[1] for o in out])):
+        v = np.frombuffer(blob, np.float32).astype(np.float64)
+        raw = float((np.maximum(v @ w1.T + b1, 0) @ w2.T + b2)[0])
+        assert got == pytest.approx(max(0.0, min(10.0, (raw + 1) * 5)), abs=1e-4)
+    assert sc.score_from_embedding(out[0][1]) == sc.scores_from_embeddings([out[0][1]])[0] and sc.scores_from_embeddings([]) == []
 
     mm.unload_model("topiq")
     assert not engine.loaded(0) and "topiq" not in mm.get_loaded_models()
