@@ -5,7 +5,9 @@ entry point raises EngineError. Only plain pointers and sizes cross the boundary
 the host buffer container.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 import threading
 
 import numpy as np
@@ -111,6 +113,28 @@ SIGNATURES = {
 }
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process. PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64; the engine links the system
+    ROCm's. Loaded in the order engine -> torch, the process ends up with two runtimes and torch reports "No HIP GPUs are
+    available" (measured: tools/hip_coexist_probe.py); in the order torch -> engine both share torch's copy and work. Facet runs
+    torch models (and RCCL through torch.distributed) next to this engine, so when a torch wheel with a bundled runtime is
+    installed its copy is mapped first - without importing torch - which makes the import order irrelevant. FACET_AMD_SYSTEM_HIP=1
+    keeps the system runtime."""
+    if os.environ.get("FACET_AMD_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass            # no bundled runtime to share: the system one is used
+
+
 def load_library():
     """dlopen the in-tree engine; raises EngineError (never falls back) when it is missing."""
     global _lib
@@ -121,6 +145,7 @@ def load_library():
             raise EngineError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _share_hip_runtime_with_torch()
         try:
             lib = C.CDLL(LIB_PATH)
         except OSError as e:
