@@ -2,20 +2,31 @@
 """Headline benchmark: images/s of the scoring hot path on synthetic 1024x1024 RGB batches.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
-   one rank per GPU, images sharded independently, per-image scores all-gathered over RCCL each step)
 
-A "step" = one pass of the hot path over one batch resident in HBM. The N=1 workload is BASELINE.json
-configs[1]: TOPIQ (ResNet-50 pyramid + CFANet head) fp32, batch 256, 1024x1024, synthetic checkpoint
-(facet_amd.weights, seed 3) and synthetic uint8 images. Per-GPU work is fixed as N grows
-(weak scaling); `value` = images all ranks scored / max-over-ranks wall time.
+N > 1 without a launcher's RANK in the environment: this process starts N fresh rank processes itself
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before anything here touches the GPU),
+relays rank 0's JSON line and exits with the children's status. Under a launcher (RANK set) it is one rank:
+one process per GPU, images sharded in contiguous blocks, one RCCL all-gather of the per-image records per step.
 
-Prints ONE JSON line (rank 0) with `roofline` (fp32-MFMA bound; achieved = algorithmic FLOPs of the timed
-region / HIP-event time on the engine stream) and `cpu_baseline` (torch-CPU oracle port on a bounded sample).
+A "step" = one pass of the hot path over one batch resident in HBM. The default workload is the one BASELINE.json's
+metric names - the TOPIQ + SAMP-Net + CLIP + InsightFace ensemble (`full`) at 1024x1024, 256 images per GPU - with
+synthetic checkpoints (facet_amd.weights, seed 3), seeded stand-in ONNX graphs of the three buffalo_l architectures and
+synthetic uint8 images. Per-GPU work is fixed as N grows (weak scaling); `value` = images all ranks
+scored / max-over-ranks wall time.
+
+Rank 0 prints ONE JSON line. Besides the contract's fields it carries
+  roofline      fp32-MFMA bound; achieved = EXECUTED FLOPs of the timed region / HIP-event time on the engine stream
+                (Winograd layers counted with the multiply-adds they really issue); `effective_tflops` is the same
+                time against the direct-convolution (algorithmic) FLOP count
+  cpu_baseline  the torch-CPU oracle port on a bounded sample of the same workload
+  sub           at N = 1: BASELINE configs[1] (TOPIQ fp32 b256) and north_star's target line (TOPIQ+CLIP forward at
+                batch 256), each timed the same way with its own roofline
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +38,24 @@ sys.path.insert(0, ROOT)
 METRIC = "images/sec whole-node (TOPIQ+SAMP+CLIP+InsightFace ensemble), 1024² batch"
 FACES_PER_IMAGE = 2
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+WORKLOADS = ["full", "topiq", "topiq_clip", "ensemble", "faces"]
+# which models a workload runs: ensemble mask (1 topiq | 2 clip | 4 samp) and whether the face stage runs
+WL = {"topiq": (1, False), "topiq_clip": (3, False), "ensemble": (7, False), "faces": (5, True), "full": (7, True)}
+
+
+def workload_text(wl, B, HW):
+    face = (f"InsightFace-style SCRFD detect @640 + 2d106 landmarks + ArcFace-R50 ({FACES_PER_IMAGE} best faces/image, seeded "
+            "stand-in ONNX graphs of the buffalo_l architectures)")
+    return {
+        "topiq": f"TOPIQ-NR (ResNet-50 pyramid + CFANet head) fp32, batch {B}/GPU, {HW}x{HW} RGB (BASELINE.json configs[1])",
+        "faces": f"TOPIQ + SAMP-Net/U2-Net-P + {face} fp32, batch {B}/GPU, {HW}x{HW} (BASELINE.json configs[2])",
+        "full": f"whole ensemble of the metric: TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP + {face} fp32, "
+                f"batch {B}/GPU, {HW}x{HW}",
+        "topiq_clip": f"TOPIQ-NR + CLIP ViT-L/14 image tower + aesthetic MLP fp32 (north_star's 'TOPIQ+CLIP forward'), "
+                      f"batch {B}/GPU, {HW}x{HW} RGB",
+        "ensemble": f"TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP fp32 (no InsightFace; the fp32 form of BASELINE "
+                    f"configs[3]), batch {B}/GPU, {HW}x{HW} RGB",
+    }[wl]
 
 
 def cpu_baseline(sample, hw, seed_w, workload="topiq"):
@@ -107,6 +136,35 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
                       f"threads on {cpu_model}; TOPIQ/SAMP one image per forward, CLIP one batch)"}
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` typed directly: start N fresh rank processes. Runs before this process imports torch or the
+    engine, so no process that touched the GPU is ever replaced or re-executed; the children's stdout (rank 0's JSON line) passes
+    through and their exit status becomes ours."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def traffic_bytes(workload, HW, B):
+    """HBM traffic of the workload from the PMC passes (profiles/rNN_traffic.json; collected with rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs of this script; gfx950 correction: FETCH_SIZE counts 64 B per 128-B request, so it is doubled -
+    /opt/skills/guides/MI355X_MICROARCH.md, HBM section). Bytes per STEP of one GPU, or None when that workload was not collected."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            tj = json.load(open(path)).get(workload)
+            if tj and tj.get("image_size") == HW:
+                return int((2.0 * tj["fetch_kb_per_image"] + tj["write_kb_per_image"]) * 1024 * B), name
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,24 +173,45 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--microbatch", type=int, default=32)
-    ap.add_argument("--workload", choices=["topiq", "topiq_clip", "ensemble", "faces", "full"], default="topiq",
-                    help="topiq = BASELINE.json configs[1]; topiq_clip = the 'TOPIQ+CLIP forward' of north_star's roofline target; ensemble = TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP; "
-                         "faces = configs[2]: TOPIQ + SAMP-Net + SCRFD/landmarks/ArcFace; full = the metric's whole ensemble "
-                         "(TOPIQ + SAMP + CLIP + InsightFace-style faces)")
-    ap.add_argument("--cpu-sample", type=int, default=4, help="images for the CPU baseline leg (0 = skip)")
+    ap.add_argument("--workload", choices=WORKLOADS, default="full",
+                    help="full = the metric's whole ensemble (TOPIQ + SAMP + CLIP + InsightFace-style faces); topiq = BASELINE.json configs[1]; "
+                         "topiq_clip = the 'TOPIQ+CLIP forward' of north_star's roofline target; ensemble = TOPIQ + SAMP-Net/U2-Net-P + CLIP "
+                         "ViT-L/14 + aesthetic MLP; faces = configs[2]: TOPIQ + SAMP-Net + SCRFD/landmarks/ArcFace")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="images for the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-sub", action="store_true", help="skip the configs[1] / TOPIQ+CLIP sub-measurements")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / gather path only, no engine (CPU test hook, gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     # the host driver of this pool only supports dmabuf IPC: RCCL needs this before the first HIP call (it is exported on the
     # GPU boxes already; set here too so a bare environment cannot break the N>1 run)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("FACET_AMD_SYNTHETIC", "1")   # no checkpoint files offline: seeded synthetic weights, stated in `config`
     import torch
     import torch.distributed as dist
+    if args.dry_run:
+        # the N > 1 control flow without a GPU: every rank gathers one record per image of its shard over gloo
+        from facet_amd.sharding import shard_range, gather_scores
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+        lo, hi = shard_range(4 * world, world, rank)
+        full = gather_scores(np.arange(lo, hi, dtype=np.float32), world)
+        ok = bool(np.array_equal(full, np.arange(4 * world, dtype=np.float32)))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "gathered_ok": ok}), flush=True)
+        sys.exit(0 if ok else 1)
     # Rehearsal knobs (not used by the driver): FACET_BENCH_BACKEND=gloo + FACET_BENCH_DEVICE=0 let two ranks share one
     # GPU so the N>1 control flow can be exercised on a 1-GPU box; the real multi-GPU run is nccl (= RCCL over xGMI).
     backend = os.environ.get("FACET_BENCH_BACKEND", "nccl")
@@ -148,19 +227,27 @@ def main():
     from facet_amd import Engine
     from facet_amd._lib import (FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_AESTHETIC, FE_MODEL_SAMP, FE_MODEL_U2NETP)
     from facet_amd.weights import synthetic_state_dict
-    from facet_amd.sharding import shard_range, gather_scores
+    from facet_amd.sharding import shard_range, gather_scores, score_shard
 
     B, HW = args.batch, args.size
+    primary = args.workload
+    subs = [] if (args.no_sub or world > 1) else [w for w in ("topiq", "topiq_clip") if w != primary]
+    need = set([primary] + subs)
+    need_mask = 0
+    for w in need:
+        need_mask |= WL[w][0]
+    need_faces = any(WL[w][1] for w in need)
+
     eng = Engine(dev_index, arena_bytes=(4 + 2 * args.microbatch * max(1, (HW * HW) // (1024 * 1024))) << 30)
     eng.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", seed=3))
-    if args.workload in ("topiq_clip", "ensemble", "full"):
+    if need_mask & 2:
         eng.load_weights(FE_MODEL_CLIP, synthetic_state_dict("clip", seed=3))
         eng.load_weights(FE_MODEL_AESTHETIC, synthetic_state_dict("aesthetic", seed=3))
-    if args.workload in ("ensemble", "faces", "full"):
+    if need_mask & 4:
         eng.load_weights(FE_MODEL_U2NETP, synthetic_state_dict("u2netp", seed=3))
         eng.load_weights(FE_MODEL_SAMP, synthetic_state_dict("samp_net", seed=3))
-    if args.workload in ("faces", "full"):
-        # BASELINE.json configs[2]: TOPIQ + SAMP-Net + InsightFace. Seeded stand-in graphs of the buffalo_l architectures
+    if need_faces:
+        # BASELINE.json configs[2] / the metric's InsightFace stage. Seeded stand-in graphs of the buffalo_l architectures
         # (no model files offline); uniform-noise images carry no real faces, so the best FACES_PER_IMAGE detections of the
         # synthetic detector go through landmarks + ArcFace (fixed faces-per-image mode).
         from facet_amd import synthetic_onnx as SO
@@ -172,6 +259,7 @@ def main():
 
     # this rank's shard of the global batch (weak scaling: B images per GPU), generated once, resident in HBM
     lo, hi = shard_range(B * world, world, rank)
+    assert hi - lo == B
     rng = np.random.default_rng([2, rank])
     d_imgs = eng.dev_alloc(B * HW * HW * 3)
     chunk = 32
@@ -187,102 +275,105 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        if args.workload in ("ensemble", "topiq_clip"):
-            rec, mask = eng.ensemble_score(images)      # [B, 789] per-image records (fields of models not loaded stay 0)
-            assert mask == (7 if args.workload == "ensemble" else 3)
-            return gather_scores(rec, world, dev_index)
-        if args.workload in ("faces", "full"):
-            rec, mask = eng.ensemble_score(images)      # faces: TOPIQ + SAMP fields only (CLIP not loaded)
-            assert mask == (5 if args.workload == "faces" else 7)
-            faces, counts, fmask = eng.face_analyze(images, (640, 640), 0.5, 0.4, FACES_PER_IMAGE)   # noise serves as BGR
-            assert fmask == 7
-            rec = np.concatenate([rec, counts[:, None].astype(np.float32), faces.reshape(B, -1)], axis=1)
-            return gather_scores(rec, world, dev_index)
-        scores = eng.topiq_score(images)
-        return gather_scores(scores, world, dev_index)
+    def make_step(wl):
+        mask, faces = WL[wl]
+        if wl == "topiq":
+            return lambda: gather_scores(eng.topiq_score(images), world, dev_index)
+        fargs = ((640, 640), 0.5, 0.4, FACES_PER_IMAGE) if faces else None      # noise serves as BGR for the face stage
 
-    for _ in range(args.warmup):
-        step()
-    eng.flops_reset()
-    barrier()
-    eng.timer_start()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        allscores = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = eng.timer_stop()
-    flops = eng.flops()
-    flops_exec = eng.flops_executed()
-    assert allscores.shape[0] == B * world and np.isfinite(allscores).all()
+        def step():
+            # records are written into a device buffer, all-gathered in place (RCCL) and copied to the host once
+            rec, ran = score_shard(eng, images, B * world, world, rank, faces=fargs)
+            assert ran == mask, (ran, mask)
+            return rec
+        return step
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
+    def measure(wl, steps, warmup):
+        eng.ensemble_select(WL[wl][0])
+        step = make_step(wl)
+        for _ in range(warmup):
+            step()
+        eng.flops_reset()
+        barrier()
+        eng.timer_start()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        ev_ms = eng.timer_stop()
+        assert out.shape[0] == B * world and np.isfinite(out).all()
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), ev_ms, eng.flops(), eng.flops_executed()
 
-    # Per-launch view of the dominant kernel family (rank 0, after the timed region): one micro-batch with a HIP event pair
-    # around every contraction launch (engine profile mode; the per-launch sync makes it slightly pessimistic). The averages
-    # are what `rocprofv3 --kernel-trace --stats` reports for conv_dma_kernel (profiles/r01_kernel_stats_bench_b64_final.csv).
-    per_launch = None
-    if rank == 0 and args.workload == "topiq":
+    def per_launch(wl):
+        """Per-launch view of the dominant kernel family (rank 0, outside the timed region): one micro-batch with a HIP event pair
+        around every contraction launch (engine profile mode; the per-launch sync makes it slightly pessimistic). The averages are
+        what `rocprofv3 --kernel-trace --stats` reports for conv_dma_kernel (profiles/)."""
         nb = min(B, args.microbatch)
+        eng.ensemble_select(WL[wl][0])
         eng.profile_enable(True)
-        eng.topiq_score((d_imgs, nb, HW, HW))
+        if wl == "topiq":
+            eng.topiq_score((d_imgs, nb, HW, HW))
+        else:
+            eng.ensemble_score((d_imgs, nb, HW, HW))
         recs = [r for r in eng.profile_records() if r["ms"] > 0]
         eng.profile_enable(False)
-        if recs:
-            tot_ms = sum(r["ms"] for r in recs)
-            tot_fl = sum(r["flops"] for r in recs)
-            per_launch = {"launches": len(recs), "avg_us": round(tot_ms / len(recs) * 1e3, 1), "images": nb,
-                          "achieved": round(tot_fl / tot_ms / 1e9, 2), "frac": round(tot_fl / tot_ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
-                          "note": "contraction launches only (conv_dma_kernel / conv_igemm_kernel / stem_kernel), algorithmic FLOPs / summed launch durations"}
+        if not recs:
+            return None
+        tot_ms = sum(r["ms"] for r in recs)
+        tot_fl = sum(r["flops"] for r in recs)
+        return {"launches": len(recs), "avg_us": round(tot_ms / len(recs) * 1e3, 1), "images": nb,
+                "effective_tflops": round(tot_fl / tot_ms / 1e9, 2),
+                "note": "contraction launches only (conv_dma_kernel / conv_igemm_kernel / stem_kernel; face graphs excluded), "
+                        "algorithmic FLOPs / summed launch durations of one micro-batch"}
 
+    def roofline(wl, steps, ev_ms, flops, flops_exec):
+        achieved = flops_exec / (ev_ms * 1e-3) / 1e12
+        traffic, tfile = traffic_bytes(wl, HW, B)
+        return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": f"bytes per step per GPU (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{tfile})" if tfile else None,
+                "kernel": "conv_dma_kernel + conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; every contraction launched in the timed region)",
+                "effective_tflops": round(flops / (ev_ms * 1e-3) / 1e12, 2),
+                "flops_per_image": round(flops / (B * steps), 1),
+                "executed_flops_per_image": round(flops_exec / (B * steps), 1),
+                "note": "achieved / frac count the FLOPs the matrix cores executed: 3x3 stride-1 pad-1 convs with >= 96 input channels run as "
+                        "Winograd F(4x4,3x3) (36 batched GEMMs per launch, 4x fewer multiply-adds); effective_tflops divides the direct "
+                        "convolution's (algorithmic) FLOPs by the same time",
+                "event_ms": round(ev_ms, 3), "per_launch": per_launch(wl) if rank == 0 else None}
+
+    dt_max, ev_ms, flops, flops_exec = measure(primary, args.steps, args.warmup)
+    out = None
     if rank == 0:
-        # HBM traffic of the same workload from the PMC passes (profiles/r01_traffic.json; collected with rocprofv3 --pmc
-        # FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this script, gfx950 correction: FETCH_SIZE counts 64 B per
-        # 128-B request, so it is doubled - /opt/skills/guides/MI355X_MICROARCH.md, HBM section). Bytes per STEP of one GPU.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath)).get(args.workload)
-            if tj and tj.get("image_size") == HW:
-                traffic = int((2.0 * tj["fetch_kb_per_image"] + tj["write_kb_per_image"]) * 1024 * B)
         total_images = B * world * args.steps
-        achieved = flops / (ev_ms * 1e-3) / 1e12
         out = {
             "metric": METRIC, "value": round(total_images / dt_max, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"TOPIQ-NR (ResNet-50 pyramid + CFANet head) fp32, batch {B}/GPU, {HW}x{HW} RGB "
-                                    "(BASELINE.json configs[1])") if args.workload == "topiq" else
-                                   (f"TOPIQ + SAMP-Net/U2-Net-P + InsightFace-style SCRFD detect @640 + 2d106 landmarks + ArcFace-R50 "
-                                    f"({FACES_PER_IMAGE} best faces/image, seeded stand-in ONNX graphs) fp32, batch {B}/GPU, {HW}x{HW} "
-                                    "(BASELINE.json configs[2])") if args.workload == "faces" else
-                                   (f"whole ensemble of the metric: TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP + InsightFace-style "
-                                    f"SCRFD@640 / 2d106 landmarks / ArcFace-R50 ({FACES_PER_IMAGE} best faces/image, stand-in ONNX graphs) fp32, "
-                                    f"batch {B}/GPU, {HW}x{HW}") if args.workload == "full" else
-                                   (f"TOPIQ-NR + CLIP ViT-L/14 image tower + aesthetic MLP fp32 (north_star's 'TOPIQ+CLIP forward'), "
-                                    f"batch {B}/GPU, {HW}x{HW} RGB") if args.workload == "topiq_clip" else
-                                   (f"ensemble TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP fp32 (no InsightFace), "
-                                    f"batch {B}/GPU, {HW}x{HW} RGB"),
+            "config": {"workload": workload_text(primary, B, HW),
                        "global_batch": B * world, "image_size": HW, "microbatch": args.microbatch,
-                       "parallelism": f"image-sharded x{world}, RCCL all-gather of scores",
-                       "weights": "seeded synthetic checkpoint (no weight files offline)"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes per step per GPU (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
-                         "kernel": "conv_dma_kernel + conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; every contraction launched in the timed region)",
-                         "flops_per_image": round(flops / (B * args.steps), 1),
-                         "executed_flops_per_image": round(flops_exec / (B * args.steps), 1),
-                         "executed_note": "3x3 stride-1 pad-1 convs with >= 96 input channels run as Winograd F(4x4,3x3) (36 batched GEMMs per launch); `achieved` counts the direct convolution's FLOPs, "
-                                          "the matrix cores executed executed_flops_per_image",
-                         "event_ms": round(ev_ms, 3), "per_launch": per_launch},
+                       "parallelism": f"image-sharded x{world}, one RCCL all-gather of per-image records per step (device buffers)",
+                       "weights": "seeded synthetic checkpoints (no weight files offline)"},
+            "roofline": roofline(primary, args.steps, ev_ms, flops, flops_exec),
         }
+    # sub-measurements (N = 1 only): BASELINE configs[1] and north_star's TOPIQ+CLIP target line, 3 timed steps each
+    sub = {}
+    for wl in subs:
+        s_steps, s_warm = 3, 1
+        dts, evs, fl, fx = measure(wl, s_steps, s_warm)
+        sub[wl] = {"value": round(B * s_steps / dts, 2), "unit": "images/s", "steps": s_steps, "warmup": s_warm,
+                   "ms_per_step": round(dts / s_steps * 1e3, 3), "dtype": "f32",
+                   "config": {"workload": workload_text(wl, B, HW)},
+                   "roofline": roofline(wl, s_steps, evs, fl, fx)}
+    if rank == 0:
+        if sub:
+            out["sub"] = sub
         if args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, HW, 3, args.workload)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, HW, 3, primary)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -22,7 +22,7 @@ FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC = 0, 1, 2
 FE_FACE_FLOATS = 739
 FE_STATS_DOUBLES = 264
 FILTERS = {"lanczos": 1, "bilinear": 2, "bicubic": 3}
-ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3}
+ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3, "softplus": 5}
 
 
 class EngineError(RuntimeError):
@@ -73,6 +73,11 @@ SIGNATURES = {
     "fe_op_layernorm": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_float, _f32p]),
     "fe_set_conv_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "fe_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int] * 12 + [_f32p]),
+    "fe_topiq_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "fe_topiq_feature_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "fe_ensemble_select": (C.c_int, [C.c_void_p, C.c_int]),
+    "fe_ensemble_score_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                        C.POINTER(C.c_int)]),
     "fe_topiq_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_topiq_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_clip_encode_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
@@ -361,11 +366,21 @@ class Engine:
         assert a.ndim == 4 and a.shape[3] == 3
         return a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], a.shape[2], 0, a
 
+    def topiq_configure(self, gate_act="gelu", weight_blk_act="gelu"):
+        """Activations of pyiqa's GatedConv used by the NEXT load_weights(FE_MODEL_TOPIQ): 'relu' | 'gelu' | 'softplus'."""
+        self._ck(self.lib.fe_topiq_configure(self.h, ACT[gate_act], ACT[weight_blk_act]))
+
+    def topiq_feature_shape(self, h, w, level):
+        """(channels, height, width) of pyramid level `level` for h x w images, as the engine computes it (conv / pool output
+        sizes, after the > 1024 LANCZOS cap)."""
+        dims = (C.c_int * 3)()
+        if self.lib.fe_topiq_feature_shape(int(h), int(w), int(level), dims) != 0:
+            raise EngineError(f"topiq_feature_shape: bad arguments h={h} w={w} level={level}")
+        return tuple(dims)
+
     def topiq_features(self, images, level):
         p, n, h, w, dev, keep = self._img_ptr(images)
-        div = [2, 4, 8, 16, 32][level]
-        ch = [64, 256, 512, 1024, 2048][level]
-        y = np.empty((n, ch, h // div, w // div), np.float32)
+        y = np.empty((n,) + self.topiq_feature_shape(h, w, level), np.float32)
         self._ck(self.lib.fe_topiq_features(self.h, p, n, h, w, dev, level, y.ctypes.data_as(_f32p)))
         return y
 
@@ -466,6 +481,20 @@ class Engine:
         mask = C.c_int(0)
         self._ck(self.lib.fe_ensemble_score(self.h, p, n, h, w, dev, rec.ctypes.data_as(_f32p), C.byref(mask)))
         return rec, mask.value
+
+    def ensemble_select(self, models=7):
+        """Which loaded models ensemble_score runs: 1 topiq | 2 clip (+ aesthetic) | 4 samp."""
+        self._ck(self.lib.fe_ensemble_select(self.h, int(models)))
+
+    def ensemble_score_dev(self, images, d_records, ld_records=FE_RECORD_FLOATS):
+        """ensemble_score with the [n, ld_records] float32 records left in device memory at `d_records` (an int address or
+        c_void_p, e.g. torch_tensor.data_ptr()); returns the models_run bitmask after the engine stream has drained."""
+        p, n, h, w, dev, keep = self._img_ptr(images)
+        mask = C.c_int(0)
+        self._ck(self.lib.fe_ensemble_score_dev(self.h, p, n, h, w, dev, C.c_void_p(int(d_records) if not isinstance(d_records, C.c_void_p)
+                                                                                     else d_records.value),
+                                                int(ld_records), C.byref(mask)))
+        return mask.value
 
     # -- ONNX graphs (InsightFace sessions) -------------------------------------------------------------
     def graph_load(self, slot, onnx_bytes):

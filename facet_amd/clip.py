@@ -11,7 +11,7 @@ tokenizer itself ships inside open_clip and is not re-implemented here (pass tok
 import numpy as np
 
 from ._lib import Engine, FE_MODEL_CLIP, FE_MODEL_AESTHETIC
-from .weights import synthetic_state_dict
+from .weights import checkpoint_or_synthetic
 
 CLIP_MEAN = np.array([0.48145466, 0.4578275, 0.40821073], np.float32)
 CLIP_STD = np.array([0.26862954, 0.26130258, 0.27577711], np.float32)
@@ -76,25 +76,26 @@ class CLIPImageModel:
         return self
 
 
-def load_clip(engine=None, weights_path=None, synthetic_seed=9):
-    """-> {'model': CLIPImageModel, 'preprocess': fn} like ModelManager._load_clip (model_manager.py:127-148)."""
+def load_clip(engine=None, weights_path=None, synthetic_seed=9, synthetic=False):
+    """-> {'model': CLIPImageModel, 'preprocess': fn} like ModelManager._load_clip (model_manager.py:127-148). Without a checkpoint
+    path this raises (the reference would download the weights or fail); synthetic=True / FACET_AMD_SYNTHETIC=1 opts into the seeded
+    stand-in checkpoint."""
     engine = engine or Engine(0)
-    if weights_path:
-        from .pyiqa_scorer import load_checkpoint
-        sd = load_checkpoint(weights_path)
-    else:
-        print("Warning: no CLIP checkpoint path given; using a seeded synthetic checkpoint")
-        sd = synthetic_state_dict('clip', synthetic_seed)
+    from .pyiqa_scorer import load_checkpoint
+    sd = checkpoint_or_synthetic('clip', weights_path, synthetic, synthetic_seed, load_checkpoint)
     return {'model': CLIPImageModel(engine, sd), 'preprocess': clip_preprocess}
 
 
 class ClipAestheticScorer:
     """`Facet.get_aesthetic_and_quality_batch` (scorer.py:640-673): one engine call for tower + normalise + MLP."""
 
-    def __init__(self, engine, clip_handle, aesthetic_state=None, synthetic_seed=9):
+    def __init__(self, engine, clip_handle, aesthetic_state=None, synthetic_seed=9, synthetic=False, aesthetic_path=None):
         self._engine = engine
         self.model, self.preprocess = clip_handle['model'], clip_handle['preprocess']
-        engine.load_weights(FE_MODEL_AESTHETIC, aesthetic_state or synthetic_state_dict('aesthetic', synthetic_seed))
+        if aesthetic_state is None:     # the reference loads the LAION aesthetic head's weights (scorer.py:560-577) or fails
+            from .pyiqa_scorer import load_checkpoint
+            aesthetic_state = checkpoint_or_synthetic('aesthetic', aesthetic_path, synthetic, synthetic_seed, load_checkpoint)
+        engine.load_weights(FE_MODEL_AESTHETIC, aesthetic_state)
 
     def get_aesthetic_and_quality_batch(self, pil_images, clip_inputs=None):
         import torch

@@ -33,6 +33,9 @@ struct fe_ctx {
   size_t samp_in_cap = 0;
   float* d_out = nullptr;   // persistent device staging for per-image results
   size_t d_out_cap = 0;
+  float* d_rec = nullptr;   // interleaved ensemble records of the host-output entry point
+  size_t d_rec_cap = 0;
+  int ensemble_mask = 7;    // models fe_ensemble_score runs when loaded: 1 topiq | 2 clip | 4 samp (fe_ensemble_select)
   float* out_buf(size_t floats) {
     if (floats > d_out_cap) {
       if (d_out) (void)hipFree(d_out);
@@ -156,6 +159,7 @@ void fe_destroy(fe_ctx* ctx) {
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
+  if (ctx->d_rec) (void)hipFree(ctx->d_rec);
   for (int i = 0; i < 2; ++i) {
     if (ctx->stage_buf[i]) (void)hipFree(ctx->stage_buf[i]);
     if (ctx->ev_copied[i]) (void)hipEventDestroy(ctx->ev_copied[i]);
@@ -276,13 +280,26 @@ int fe_weights_set(fe_ctx* ctx, int model, const char* name, const float* data, 
   ctx->c.staging[model].set(name, data, shape, ndim);
   FE_API_END(ctx)
 }
+int fe_topiq_configure(fe_ctx* ctx, int gate_act, int weight_blk_act) {
+  FE_API_BEGIN(ctx)
+  auto ok = [](int a) { return a == FE_ACT_RELU || a == FE_ACT_GELU || a == FE_ACT_SOFTPLUS; };
+  FE_CHECK(ok(gate_act) && ok(weight_blk_act), "topiq_configure: activations must be relu, gelu or softplus");
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  ctx->c.topiq_gate_act = gate_act;
+  ctx->c.topiq_wblk_act = weight_blk_act;
+  FE_API_END(ctx)
+}
+
 int fe_weights_commit(fe_ctx* ctx, int model) {
   FE_API_BEGIN(ctx)
+  FE_CHECK(model >= 0 && model < 8, "model id %d", model);
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   FE_HIP(hipSetDevice(ctx->c.device));
   WeightStore& ws = ctx->c.staging[model];
   if (model == FE_MODEL_TOPIQ) {
     auto m = std::make_unique<TopiqModel>();
+    m->gate_act = ctx->c.topiq_gate_act;
+    m->wblk_act = ctx->c.topiq_wblk_act;
     const int blocks[4] = {3, 4, 6, 3};
     build_resnet(m->backbone, m->dw, ws, "semantic_model.", true, blocks, false);
     if (ws.has("weight_pool.0.splitconv.weight")) build_topiq_head(*m, ws);
@@ -605,6 +622,21 @@ static void topiq_backbone_chunk(fe_ctx* ctx, const uint8_t* d_rgb, int nb, int 
   resnet_forward(C, ctx->c.topiq->backbone, x, &feats);
 }
 
+int fe_topiq_feature_shape(int h, int w, int level, int dims[3]) {
+  if (!dims || h < 32 || w < 32 || level < 0 || level > 4) return FE_ERR_INVALID;
+  const int long_edge = h > w ? h : w;
+  if (long_edge > 1024) {   // the LANCZOS cap of PyIQAScorer._preprocess_image, as topiq_backbone_chunk applies it
+    const double sc = 1024.0 / long_edge;
+    w = (int)(w * sc); h = (int)(h * sc);
+  }
+  static const int ch[5] = {64, 256, 512, 1024, 2048};
+  int fh = conv_out_dim(h, 7, 2, 3, 1), fw = conv_out_dim(w, 7, 2, 3, 1);              // stem 7x7 / 2
+  if (level >= 1) { fh = conv_out_dim(fh, 3, 2, 1, 1); fw = conv_out_dim(fw, 3, 2, 1, 1); }   // max pool 3x3 / 2
+  for (int l = 2; l <= level; ++l) { fh = conv_out_dim(fh, 3, 2, 1, 1); fw = conv_out_dim(fw, 3, 2, 1, 1); }   // stride-2 3x3 of layer l
+  dims[0] = ch[level]; dims[1] = fh; dims[2] = fw;
+  return FE_OK;
+}
+
 int fe_topiq_features(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, int level, float* out) {
   FE_API_BEGIN(ctx)
   Ctx& C = ctx->c;
@@ -715,6 +747,15 @@ int fe_samp_forward(fe_ctx* ctx, const float* x, int n, float* pattern_weights, 
 // to a third of a launch. tools/clip_mb_sweep.py: 621 img/s at 32 images per launch, ~700 at 95-127. So crops (602 KB each)
 // are collected across micro-batches and the tower runs on `chunk` of them, chunk chosen for full rounds.
 extern "C++" {
+// Moves the `left` crops behind the `c` just consumed to the front of a batcher buffer. left can exceed c (micro-batch larger than
+// the tower chunk), where one copy would have overlapping source and destination ranges: the move is cut into pieces of at most c
+// crops, each with disjoint ranges, issued in ascending order on the one stream.
+static void compact_crops(float* buf, size_t per, int c, int left, hipStream_t s) {
+  for (int done = 0; done < left; done += c) {
+    const int n = std::min(c, left - done);
+    FE_HIP(hipMemcpyAsync(buf + (size_t)done * per, buf + (size_t)(c + done) * per, (size_t)n * per * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+}
 static int clip_tower_chunk(const ClipModel& m, int n) {
   if (n <= 40) return n;
   const int hi = std::min(n, 128), lo = std::max(32, hi - 40), ntile = std::max(1, m.width / 128);
@@ -765,9 +806,8 @@ class ClipBatcher {
     if (norm_) l2_normalize(C, feat_ + (size_t)done_ * od_, norm_ + (size_t)done_ * od_, c, od_);
     if (aes_) aesthetic_forward(C, *C.aesthetic, feat_ + (size_t)done_ * od_, c, aes_ + done_);
     C.arena.rewind(mark);
-    const int left = count_ - c;   // < chunk_ = c whenever a full chunk ran, so source and destination cannot overlap
-    if (left > 0)
-      FE_HIP(hipMemcpyAsync(x_->clip_in, x_->clip_in + (size_t)c * per_, (size_t)left * per_ * sizeof(float), hipMemcpyDeviceToDevice, C.stream));
+    const int left = count_ - c;
+    compact_crops(x_->clip_in, per_, c, left, C.stream);
     done_ += c;
     count_ = left;
   }
@@ -815,8 +855,7 @@ class SampBatcher {
     sampnet_forward(C, *C.samp, x, sal, pw_ + (size_t)done_ * 8, at_ + (size_t)done_ * 6, sd_ + (size_t)done_ * 5);
     C.arena.rewind(mark);
     const int left = count_ - c;
-    if (left > 0)
-      FE_HIP(hipMemcpyAsync(x_->samp_in, x_->samp_in + (size_t)c * per_, (size_t)left * per_ * sizeof(float), hipMemcpyDeviceToDevice, C.stream));
+    compact_crops(x_->samp_in, per_, c, left, C.stream);
     done_ += c;
     count_ = left;
   }
@@ -1044,21 +1083,37 @@ int fe_tag_similarities(fe_ctx* ctx, const float* emb, int n, const float* text,
 // One call per batch for the whole ensemble (what processing/batch_processor.py:169-360 sequences per image):
 // record[i] = [topiq_raw, aesthetic_raw, pattern_weights(8), attributes(6), score_dist(5), clip_emb_norm(768)] = 789 floats.
 // Models that are not loaded leave their fields at 0 (mask bit i of *models_run: 1 topiq, 2 clip, 4 samp).
-int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* records, int* models_run) {
-  FE_API_BEGIN(ctx)
+extern "C++" {
+// SoA result planes (what the model heads write) -> [n][ld] records, one thread per record float.
+__global__ void records_interleave_kernel(const float* __restrict__ planes, size_t n4, int n, float* __restrict__ rec, int ld) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n * FE_RECORD_FLOATS) return;
+  const int img = (int)(i / FE_RECORD_FLOATS), f = (int)(i - (size_t)img * FE_RECORD_FLOATS);
+  const size_t o_aes = n4, o_pw = 2 * n4, o_at = o_pw + 8 * n4, o_sd = o_at + 6 * n4, o_emb = o_sd + 5 * n4;
+  float v;
+  if (f == 0) v = planes[img];
+  else if (f == 1) v = planes[o_aes + img];
+  else if (f < 10) v = planes[o_pw + (size_t)img * 8 + (f - 2)];
+  else if (f < 16) v = planes[o_at + (size_t)img * 6 + (f - 10)];
+  else if (f < 21) v = planes[o_sd + (size_t)img * 5 + (f - 16)];
+  else v = planes[o_emb + (size_t)img * 768 + (f - 21)];
+  rec[(size_t)img * ld + f] = v;
+}
+
+// Runs every selected model over the batch and leaves the interleaved records in device memory d_rec [n][ld].
+static int ensemble_run(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* d_rec, int ld) {
   Ctx& C = ctx->c;
-  FE_CHECK(rgb && records && n > 0 && h >= 32 && w >= 32, "bad arguments");
-  const int R = FE_RECORD_FLOATS;
   const size_t per = (size_t)h * w * 3;
-  // SoA planes on the device (every plane 16-B aligned), interleaved into records on the host copy
+  // SoA planes on the device (every plane 16-B aligned), interleaved into records by a last small kernel
   const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
   const size_t o_aes = n4, o_pw = 2 * n4, o_at = o_pw + 8 * n4, o_sd = o_at + 6 * n4, o_emb = o_sd + 5 * n4,
                o_feat = o_emb + 768 * n4, total = o_feat + 768 * n4;
-  float* d_rec = ctx->out_buf(total);
-  FE_HIP(hipMemsetAsync(d_rec, 0, total * sizeof(float), C.stream));
-  const bool do_topiq = C.topiq && C.topiq->has_head, do_clip = (bool)C.clip, do_samp = C.samp && C.u2netp;
-  float* p_topiq = d_rec;  float* p_aes = d_rec + o_aes;  float* p_pw = d_rec + o_pw;  float* p_at = d_rec + o_at;
-  float* p_sd = d_rec + o_sd;  float* p_emb = d_rec + o_emb;  float* d_feat = d_rec + o_feat;
+  float* d_pl = ctx->out_buf(total);
+  FE_HIP(hipMemsetAsync(d_pl, 0, total * sizeof(float), C.stream));
+  const int sel = ctx->ensemble_mask;
+  const bool do_topiq = (sel & 1) && C.topiq && C.topiq->has_head, do_clip = (sel & 2) && C.clip, do_samp = (sel & 4) && C.samp && C.u2netp;
+  float* p_topiq = d_pl;  float* p_aes = d_pl + o_aes;  float* p_pw = d_pl + o_pw;  float* p_at = d_pl + o_at;
+  float* p_sd = d_pl + o_sd;  float* p_emb = d_pl + o_emb;  float* d_feat = d_pl + o_feat;
   std::unique_ptr<ClipBatcher> tower;
   if (do_clip) tower = std::make_unique<ClipBatcher>(ctx, n, ctx->microbatch, d_feat, p_emb, C.aesthetic ? p_aes : nullptr);
   std::unique_ptr<SampBatcher> samp;
@@ -1091,18 +1146,48 @@ int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
   }
   if (tower) tower->finish();
   if (samp) samp->finish();
-  std::vector<float> host(o_feat);
-  FE_HIP(hipMemcpyAsync(host.data(), d_rec, host.size() * sizeof(float), hipMemcpyDeviceToHost, C.stream));
-  FE_HIP(hipStreamSynchronize(C.stream));
-  for (int i = 0; i < n; ++i) {
-    float* r = records + (size_t)i * R;
-    r[0] = host[i]; r[1] = host[o_aes + i];
-    memcpy(r + 2, &host[o_pw + (size_t)i * 8], 8 * sizeof(float));
-    memcpy(r + 10, &host[o_at + (size_t)i * 6], 6 * sizeof(float));
-    memcpy(r + 16, &host[o_sd + (size_t)i * 5], 5 * sizeof(float));
-    memcpy(r + 21, &host[o_emb + (size_t)i * 768], 768 * sizeof(float));
+  const size_t work = (size_t)n * FE_RECORD_FLOATS;
+  hipLaunchKernelGGL(records_interleave_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, C.stream, d_pl, n4, n, d_rec, ld);
+  FE_HIP(hipGetLastError());
+  return (do_topiq ? 1 : 0) | (do_clip ? 2 : 0) | (do_samp ? 4 : 0);
+}
+}  // extern "C++"
+
+int fe_ensemble_select(fe_ctx* ctx, int models) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(models > 0 && models <= 7, "ensemble_select: mask %d (1 topiq | 2 clip | 4 samp)", models);
+  ctx->ensemble_mask = models;
+  FE_API_END(ctx)
+}
+
+int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* records, int* models_run) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(rgb && records && n > 0 && h >= 32 && w >= 32, "bad arguments");
+  const size_t floats = (size_t)n * FE_RECORD_FLOATS;
+  if (floats > ctx->d_rec_cap) {
+    if (ctx->d_rec) FE_HIP(hipFree(ctx->d_rec));
+    ctx->d_rec = nullptr; ctx->d_rec_cap = 0;
+    FE_HIP(hipMalloc((void**)&ctx->d_rec, floats * sizeof(float)));
+    ctx->d_rec_cap = floats;
   }
-  if (models_run) *models_run = (do_topiq ? 1 : 0) | (do_clip ? 2 : 0) | (do_samp ? 4 : 0);
+  const int ran = ensemble_run(ctx, rgb, n, h, w, on_device, ctx->d_rec, FE_RECORD_FLOATS);
+  FE_HIP(hipMemcpyAsync(records, ctx->d_rec, floats * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  if (models_run) *models_run = ran;
+  FE_API_END(ctx)
+}
+
+// Same, with the records left in DEVICE memory: d_records [n][ld_records] floats (ld_records >= FE_RECORD_FLOATS; the columns past
+// 789 are not touched, so a caller can keep its face slots beside them). Returns after the engine stream has drained, so the
+// buffer can be handed to a collective on another stream (the multi-GPU all-gather reads it in place: facet_amd/sharding.py).
+int fe_ensemble_score_dev(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* d_records, int ld_records,
+                          int* models_run) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(rgb && d_records && n > 0 && h >= 32 && w >= 32 && ld_records >= FE_RECORD_FLOATS, "bad arguments");
+  const int ran = ensemble_run(ctx, rgb, n, h, w, on_device, d_records, ld_records);
+  FE_HIP(hipStreamSynchronize(ctx->c.stream));
+  if (models_run) *models_run = ran;
   FE_API_END(ctx)
 }
 

@@ -27,8 +27,10 @@ class WeightStore {
 // Owns device copies of packed weights for one model; freed together.
 class DeviceWeights {
  public:
+  int prec = 0;   // Precision the owning model is built for: pack_conv also emits the bf16 forms when PREC_BF16
   ~DeviceWeights() { release(); }
   float* upload(const std::vector<float>& v);
+  void* upload_raw(const void* data, size_t bytes);   // any element type (bf16 weights)
   void release();
   size_t bytes() const { return bytes_; }
  private:
@@ -44,7 +46,20 @@ struct LayerNormW {
   float* g = nullptr; float* b = nullptr; int d = 0; float eps = 1e-5f;
 };
 
+// Precision of a model's activations / weights, chosen per context before fe_weights_commit (fe_set_precision).
+enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1 };
+// round-to-nearest-even float -> bf16 bits on the host (NaN stays NaN)
+inline uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+// Adds the bf16 forms (ConvW.wh / wtap_h) of a weight to an already packed ConvW; a no-op for layers the bf16 kernel cannot take
+// (3-channel first layers: those run on the fp32 stem / generic kernels and hand a bf16 tensor to the next layer).
+void pack_conv_bf16(DeviceWeights& dw, const HostTensor& w, ConvW& c);
+
 // Build helpers ------------------------------------------------------------------------------------
+// `bf16` below: also build the bf16 form (models committed under PREC_BF16).
 // packs an OIHW (or [out][in]) weight for the conv kernels; scale/shift are per-Cout epilogue vectors (nullable)
 ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>* scale, const std::vector<float>* shift);
 // conv (OIHW) with optional bias and optional eval-mode BatchNorm folded into per-channel scale/shift.
@@ -62,6 +77,7 @@ struct Ctx;
 struct MHAW {
   ConvW q, k;          // projections with bias; q carries the 1/sqrt(head_dim) scaling in scale/shift
   float* wv = nullptr; // raw [d][d] V weight: used as the A operand so the GEMM emits V^T directly
+  bf16* wv_h = nullptr; // the same in bf16 (PREC_BF16 models)
   float* bv = nullptr; // [d] V bias, added after P.V (softmax rows sum to 1)
   ConvW out;           // out_proj
   int d = 0, heads = 0;
@@ -126,6 +142,8 @@ struct Ctx {
   double flops_accum = 0.0;
   double flops_saved = 0.0;   // algorithmic FLOPs NOT executed because a layer ran as Winograd (executed = flops_accum - flops_saved)
   int force_variant = 0;   // developer hook: forwarded to ConvParams.variant
+  // TOPIQ GatedConv activations picked up by the next fe_weights_commit(FE_MODEL_TOPIQ) (fe_topiq_configure)
+  int topiq_gate_act = ACT_GELU, topiq_wblk_act = ACT_GELU;
 
   std::map<std::tuple<int, int, int>, ResizeCoeffsDev> resize_cache;  // (in, out, filter) -> device tables
   WeightStore staging[8];
@@ -148,6 +166,8 @@ struct TopiqModel {
   DeviceWeights dw;
   ResNet backbone;
   bool has_head = false;
+  int gate_act = ACT_GELU;   // activation of the gated branch x1 (pyiqa GatedConv.act)
+  int wblk_act = ACT_GELU;   // activation after weight_blk[0] and weight_blk[2]
   GatedConvW gate[5];
   ConvW dim_reduce[5];
   EncLayerW sa[5];

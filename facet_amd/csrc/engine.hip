@@ -27,6 +27,14 @@ float* DeviceWeights::upload(const std::vector<float>& v) {
   bytes_ += b;
   return (float*)p;
 }
+void* DeviceWeights::upload_raw(const void* data, size_t bytes) {
+  void* p = nullptr;
+  FE_HIP(hipMalloc(&p, bytes ? bytes : 16));
+  if (bytes) FE_HIP(hipMemcpy(p, data, bytes, hipMemcpyHostToDevice));
+  ptrs_.push_back(p);
+  bytes_ += bytes;
+  return p;
+}
 void DeviceWeights::release() {
   for (void* p : ptrs_) (void)hipFree(p);
   ptrs_.clear();
@@ -116,7 +124,44 @@ ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>
   }
   if (scale) c.scale = dw.upload(*scale);
   if (shift) c.shift = dw.upload(*shift);
+  if (dw.prec == PREC_BF16) pack_conv_bf16(dw, w, c);
   return c;
+}
+
+// bf16 form: [Cout][KpH], K order = channel block (cb) outer, tap inner, channel-in-block innermost (kernels_conv_bf16.hip);
+// 1x1 kernels keep plain channel order with Cin rounded up to 8 (the kernel zero-fills the chunk past Cin).
+void pack_conv_bf16(DeviceWeights& dw, const HostTensor& w, ConvW& c) {
+  const int ntaps = c.KH * c.KW;
+  c.CinPadH = (c.Cin + 7) & ~7;
+  if (ntaps > 1) {
+    if (c.CinPadH % 32 == 0) c.cb = 32;
+    else if (c.CinPadH % 16 == 0) c.cb = 16;
+    else return;                       // 3-channel first layers: no bf16 form (fp32 stem / generic kernel, bf16 output)
+    if (ntaps >= 64) return;
+  } else {
+    c.cb = 32;
+  }
+  const int K = ntaps * c.CinPadH;
+  c.KpH = (K + CONV_KALIGN_H - 1) / CONV_KALIGN_H * CONV_KALIGN_H;
+  std::vector<uint16_t> packed((size_t)c.Cout * c.KpH, 0);
+  for (int co = 0; co < c.Cout; ++co)
+    for (int ci = 0; ci < c.Cin; ++ci)
+      for (int t = 0; t < ntaps; ++t) {
+        const size_t k = ntaps > 1 ? ((size_t)(ci / c.cb) * ntaps + t) * c.cb + (ci % c.cb) : (size_t)ci;
+        packed[(size_t)co * c.KpH + k] = f32_to_bf16_bits(w.data[((size_t)co * c.Cin + ci) * ntaps + t]);
+      }
+  c.wh = (bf16*)dw.upload_raw(packed.data(), packed.size() * sizeof(uint16_t));
+  if (c.Cout <= 2 && ntaps > 1) {
+    // tap-decomposed form (see pack_conv): rows (tap, co) of a 1x1 conv, row count rounded up to 8 for 16-byte stores
+    const int T = ntaps * c.Cout, T8 = (T + 7) & ~7;
+    c.KpTH = (c.CinPadH + CONV_KALIGN_H - 1) / CONV_KALIGN_H * CONV_KALIGN_H;
+    std::vector<uint16_t> tp((size_t)T8 * c.KpTH, 0);
+    for (int t = 0; t < ntaps; ++t)
+      for (int co = 0; co < c.Cout; ++co)
+        for (int ci = 0; ci < c.Cin; ++ci)
+          tp[(size_t)(t * c.Cout + co) * c.KpTH + ci] = f32_to_bf16_bits(w.data[((size_t)co * c.Cin + ci) * ntaps + t]);
+    c.wtap_h = (bf16*)dw.upload_raw(tp.data(), tp.size() * sizeof(uint16_t));
+  }
 }
 
 ConvW build_conv(DeviceWeights& dw, const WeightStore& ws, const std::string& conv_prefix,
@@ -453,6 +498,11 @@ MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& pref
   std::vector<float> bv(Bv.data.begin() + 2 * d, Bv.data.begin() + 3 * d);
   m.wv = dw.upload(wv);
   m.bv = dw.upload(bv);
+  if (dw.prec == PREC_BF16) {
+    std::vector<uint16_t> wvh(wv.size());
+    for (size_t i = 0; i < wv.size(); ++i) wvh[i] = f32_to_bf16_bits(wv[i]);
+    m.wv_h = (bf16*)dw.upload_raw(wvh.data(), wvh.size() * sizeof(uint16_t));
+  }
   m.out = build_linear(dw, ws, prefix + ".out_proj", true);
   return m;
 }

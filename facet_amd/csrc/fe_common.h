@@ -39,23 +39,40 @@ inline void ensure_dynamic_lds(const void* kernel, size_t bytes, std::atomic<uin
 }
 
 // Activation codes shared by the GEMM/conv epilogue.
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_PRELU = 4 };  // PRELU: per-channel slope
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_PRELU = 4, ACT_SOFTPLUS = 5 };  // PRELU: per-channel slope
 
-// A view of an NHWC fp32 activation in HBM. `ld` is the channel stride of one pixel
-// (>= c) so a view can be a channel slice of a wider (concat) buffer.
-struct Tensor {
-  float* p = nullptr;
+// Scalar activations of the contraction epilogues (PReLU is handled by the callers: it needs the per-channel slope).
+// Softplus follows torch.nn.Softplus(beta=1, threshold=20): x above the threshold passes through.
+__device__ __forceinline__ float fe_apply_act(float v, int act) {
+  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  if (act == ACT_SOFTPLUS) return v > 20.f ? v : log1pf(expf(v));
+  return v;
+}
+
+// bf16 storage type of the reduced-precision path (BASELINE configs[3]). hipcc lowers float <-> __bf16 casts to
+// v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN) / a 16-bit shift.
+typedef __bf16 bf16;
+
+// A view of an NHWC activation in HBM (T = float, or bf16 on the reduced-precision path). `ld` is the channel stride of one
+// pixel (>= c) so a view can be a channel slice of a wider (concat) buffer.
+template <class T>
+struct TensorT {
+  T* p = nullptr;
   int n = 0, h = 0, w = 0, c = 0;
   int ld = 0;
   size_t pixels() const { return (size_t)n * h * w; }
   size_t numel() const { return pixels() * c; }
-  Tensor slice(int c0, int cn) const {
-    Tensor t = *this;
+  TensorT slice(int c0, int cn) const {
+    TensorT t = *this;
     t.p = p + c0;
     t.c = cn;
     return t;
   }
 };
+using Tensor = TensorT<float>;
+using TensorH = TensorT<bf16>;
 
 // Bump allocator over one hipMalloc'ed slab; reset per forward. 256-B aligned.
 class Arena {
@@ -84,12 +101,16 @@ class Arena {
     if (off_ > high_) high_ = off_;
     return (char*)base_ + a;
   }
-  Tensor tensor(int n, int h, int w, int c) {
-    Tensor t;
+  template <class T>
+  TensorT<T> tensor_t(int n, int h, int w, int c) {
+    TensorT<T> t;
     t.n = n; t.h = h; t.w = w; t.c = c; t.ld = c;
-    t.p = (float*)alloc(t.numel() * sizeof(float));
+    t.p = (T*)alloc(t.numel() * sizeof(T));
     return t;
   }
+  Tensor tensor(int n, int h, int w, int c) { return tensor_t<float>(n, h, w, c); }
+  template <class T>
+  T* array(size_t count) { return (T*)alloc(count * sizeof(T)); }
  private:
   void* base_ = nullptr;
   size_t cap_ = 0, off_ = 0, high_ = 0;
@@ -98,15 +119,16 @@ class Arena {
 // ---------------------------------------------------------------------------------------
 // Implicit-GEMM convolution / GEMM (kernels_conv.hip)
 // ---------------------------------------------------------------------------------------
-struct ConvParams {
-  const float* x; int ldx;          // input NHWC view
-  const float* w;                   // packed [Cout][Kp], k = (kh, kw, ci) with ci fastest, zero padded to Kp
+template <class T>
+struct ConvParamsT {
+  const T* x; int ldx;              // input NHWC view
+  const T* w;                       // packed [Cout][Kp], zero padded to Kp; K order: see pack_conv (fp32) / pack_conv_bf16
   const float* scale;               // per-Cout multiply (nullable => 1)
   const float* shift;               // per-Cout add (nullable => 0)
   const float* slope;               // per-Cout negative slope, ACT_PRELU only
-  const float* res; int ldr;        // residual view, same N,Ho,Wo,Cout (nullable)
-  const float* gate; int ldg;       // multiplicative gate, ldg==... (nullable); gate_c1: single channel broadcast
-  float* y; int ldy;                // output NHWC view
+  const T* res; int ldr;            // residual view, same N,Ho,Wo,Cout (nullable)
+  const T* gate; int ldg;           // multiplicative gate, ldg==... (nullable); gate_c1: single channel broadcast
+  T* y; int ldy;                    // output NHWC view
   int N, H, W, Cin, Ho, Wo, Cout;
   int KH, KW, sh, sw, ph, pw, dh, dw;
   int K, Kp, M;
@@ -114,13 +136,17 @@ struct ConvParams {
   int res_after_act;                // 1: y = act(conv*scale+shift) + res ; 0: y = act(conv*scale+shift+res)
   int gate_c1;                      // 1: gate has one channel (broadcast over Cout)
   int vec_epi;                      // set by launch_conv: 16-B vector epilogue is legal
-  int ldw;                          // weight row stride in floats (0 => Kp); lets an activation matrix act as B
+  int ldw;                          // weight row stride in elements (0 => Kp); lets an activation matrix act as B
   // batched launches (gridDim.y = batch): b = bo*nb1 + bi; pointer += bo*s2 + bi*s1 (element strides)
   int batch, nb1;
   long long xs1, xs2, ws1, ws2, ys1, ys2, hs1;   // hs1: shift stride per inner index
   int buf_ok; unsigned x_span, w_span;  // set by launch_conv_dma: operands addressable through 32-bit buffer offsets
   int variant;                      // 0 = auto tile choice; >0 forces a tile variant (tools/conv_bench.py)
+  int cb;                           // bf16 kernel: channel block of the packed K order (32, or 16 for Cin % 32 != 0 spatial kernels)
+  int pad_store;                    // bf16 kernel: columns [Cout, roundup8(Cout)) exist in y and are written as zeros (V^T GEMM)
 };
+using ConvParams = ConvParamsT<float>;
+using ConvParamsH = ConvParamsT<bf16>;
 
 // Packed conv weight living in HBM.
 struct ConvW {
@@ -136,17 +162,25 @@ struct ConvW {
   float* wino = nullptr;   // 3x3 convs with Cin >= 256 also carry Winograd F(2x2,3x3) weights U[16][Cout][Cin]
   float* wstem = nullptr;  // 7x7 or 3x3, Cin <= 3, Cout 32|64 stems also carry the [taps][Cout][4] layout of kernels_stem.hip
   int KpT = 0;
+  // bf16 path (models committed under FE_PRECISION_BF16): [Cout][KpH] bf16 in the K order of kernels_conv_bf16.hip
+  bf16* wh = nullptr;
+  int KpH = 0, cb = 0, CinPadH = 0;   // CinPadH: input channels the bf16 kernel reads per pixel (Cin rounded up to 8)
+  bf16* wtap_h = nullptr;  // tap-decomposed form for Cout <= 2 spatial kernels, [KH*KW*Cout rounded to 8][KpTH]
+  int KpTH = 0;
 };
 
-struct ConvOpts {
+template <class T>
+struct ConvOptsT {
   int sh = 1, sw = 1, ph = 0, pw = 0, dh = 1, dw = 1;
   int act = ACT_NONE;
-  const Tensor* res = nullptr;
+  const TensorT<T>* res = nullptr;
   int res_after_act = 0;
-  const Tensor* gate = nullptr;
+  const TensorT<T>* gate = nullptr;
 };
+using ConvOpts = ConvOptsT<float>;
 
 constexpr int CONV_KALIGN = 32;  // Kp is a multiple of this (covers BK = 16 and 32)
+constexpr int CONV_KALIGN_H = 64; // bf16 kernel: K padded to whole K-steps of two 32-element slabs
 
 void launch_conv(const ConvParams& p, hipStream_t s);
 // Winograd transforms (kernels_winograd.hip): V / M are [16][tiles][C] planes
@@ -159,6 +193,7 @@ bool launch_stem(const float* x, int ldx, int N, int H, int W, const float* wste
                  int Cout, int k, int stride, int act, float* y, int ldy, int Ho, int Wo, hipStream_t s);   // kernels_stem.hip; false = shape not handled
 void launch_conv_narrow(const ConvParams& p, hipStream_t s);            // Cout <= 4, no MFMA (kernels_misc.hip)
 void launch_conv_dma(const ConvParams& p, int tile, hipStream_t s);  // LDS-DMA fast path (kernels_conv_dma.hip)
+void launch_conv_bf16(const ConvParamsH& p, hipStream_t s);          // bf16 MFMA implicit GEMM (kernels_conv_bf16.hip)
 double conv_flops(const ConvParams& p);
 
 // ---------------------------------------------------------------------------------------
@@ -167,41 +202,47 @@ double conv_flops(const ConvParams& p);
 // u8 HWC RGB -> fp32 NHWC4 ((v/255 - mean)/std, 4th channel 0). bgr: input channel order is BGR.
 void launch_u8_to_nhwc4_norm(const uint8_t* src, float* dst, size_t pixels, const float mean[3],
                              const float stdv[3], int bgr, hipStream_t s);
+// The helper kernels below are templates over the activation element type T (float | bf16; arithmetic is fp32 in both),
+// explicitly instantiated in kernels_misc.hip.
 // fp32 NCHW -> NHWC(c padded to cpad with zeros)
-void launch_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, int cpad,
-                         hipStream_t s);
-void launch_nhwc_to_nchw(const float* src, int lds_, float* dst, int n, int c, int h, int w,
-                         hipStream_t s);
+template <class T> void launch_nchw_to_nhwc(const float* src, T* dst, int n, int c, int h, int w, int cpad, hipStream_t s);
+template <class T> void launch_nhwc_to_nchw(const T* src, int lds_, float* dst, int n, int c, int h, int w, hipStream_t s);
 // max pool, NHWC; ceil_mode handled by caller through Ho/Wo; padding implicit -inf.
-void launch_maxpool(const Tensor& x, const Tensor& y, int k, int stride, int pad, hipStream_t s);
+template <class T> void launch_maxpool(const TensorT<T>& x, const TensorT<T>& y, int k, int stride, int pad, hipStream_t s);
 // bilinear resize (align_corners=False), NHWC.
-void launch_bilinear(const Tensor& x, const Tensor& y, hipStream_t s);
+template <class T> void launch_bilinear(const TensorT<T>& x, const TensorT<T>& y, hipStream_t s);
 // adaptive average pool NHWC -> NHWC (torch semantics: start=floor(i*H/Ho), end=ceil((i+1)*H/Ho))
-void launch_adaptive_avgpool(const Tensor& x, const Tensor& y, hipStream_t s);
+template <class T> void launch_adaptive_avgpool(const TensorT<T>& x, const TensorT<T>& y, hipStream_t s);
+void launch_convert(const float* x, bf16* y, size_t n, hipStream_t s);
+void launch_convert(const bf16* x, float* y, size_t n, hipStream_t s);
 void launch_splitk_reduce(const float* part, int splits, int M, int N, const float* scale, const float* shift, const float* slope, int act,
                           const float* res, int ldr, int res_after_act, float* y, int ldy, hipStream_t s);
 // y = act(x) elementwise / y = x + r
 // y[n,oh,ow,co] = act(scale*sum_tap z[n, oh-ph+kh*dh, ow-pw+kw*dw, tap*Cout+co] + shift)  (stride 1)
-void launch_tap_gather(const float* z, int ldz, int n, int h, int w, int kh, int kw, int ph, int pw, int dh, int dw,
-                       int cout, const float* scale, const float* shift, int act, float* y, int ldy, int ho, int wo,
+template <class T>
+void launch_tap_gather(const T* z, int ldz, int n, int h, int w, int kh, int kw, int ph, int pw, int dh, int dw,
+                       int cout, const float* scale, const float* shift, int act, T* y, int ldy, int ho, int wo,
                        hipStream_t s);
 // fused attention, head_dim 64 (kernels_attn.hip): o = softmax(q k^T) v + bv per (batch, head)
 void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* vt, int lp, const float* bv, float* o,
                       int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s);
-// M <= 32 rows: one wave per output column (kernels_misc.hip)
-void launch_gemm_skinny(const float* x, int ldx, const float* w, int ldw, const float* scale, const float* shift, float* y,
+// M <= 32 rows: one wave per output column (kernels_misc.hip); TI / TW / TO = activation / weight / output element types
+template <class TI, class TW, class TO>
+void launch_gemm_skinny(const TI* x, int ldx, const TW* w, int ldw, const float* scale, const float* shift, TO* y,
                         int ldy, int M, int N, int K, int act, hipStream_t s);
 void launch_sigmoid(const Tensor& x, const Tensor& y, hipStream_t s);
 void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s);
-// LayerNorm over last dim of a [rows][d] matrix (eps inside sqrt, biased variance)
-void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b,
+// LayerNorm over last dim of a [rows][d] matrix (eps inside sqrt, biased variance); statistics in fp32
+template <class T>
+void launch_layernorm(const T* x, int ldx, T* y, int ldy, const float* g, const float* b,
                       int rows, int d, float eps, hipStream_t s);
 // rows softmax in place for [rows][d]
 void launch_softmax_rows(float* x, int ld, int rows, int d, hipStream_t s);
 // same, and zero-fills columns [d, ld) so the padded tail contributes nothing to P.V
 void launch_softmax_rows_pad(float* x, int ld, int rows, int d, hipStream_t s);
 // y[rows][d] += pos[(row % L)][d]
-void launch_add_rows_bcast(float* y, int ldy, const float* pos, int rows, int L, int d, hipStream_t s);
+template <class T>
+void launch_add_rows_bcast(T* y, int ldy, const float* pos, int rows, int L, int d, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // Graph-runtime kernels (kernels_graph.hip); channel counts are multiples of 4

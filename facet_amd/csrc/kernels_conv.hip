@@ -22,12 +22,7 @@ namespace fe {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-  if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
-  return v;
-}
+__device__ __forceinline__ float apply_act(float v, int act) { return fe_apply_act(v, act); }
 
 template <int WGM, int WGN, int TM, int TN, int BK, bool FAST>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p, const int ntiles) {

@@ -1,0 +1,455 @@
+// Implicit-GEMM convolution / GEMM on the bf16 matrix cores of gfx950 (v_mfma_f32_32x32x16_bf16, fp32 accumulate): the contraction
+// kernel of the reduced-precision path (BASELINE.json configs[3]: TOPIQ + SAMP-Net + CLIP ViT-L/14 in bf16; the reference itself runs
+// CLIP in half precision on a GPU, processing/scorer.py:513-516). bf16 NHWC activations and bf16 packed weights in HBM, fp32
+// accumulators, fp32 per-channel scale / shift (folded BatchNorm, bias), fp32 activation math, one rounding to bf16 at the store.
+//
+//   Y[m][co] = act( (sum_k A[m][k] * Wt[co][k]) * scale[co] + shift[co] (+ res[m][co]) ) (* gate[m])
+//
+// Structure = conv_dma_kernel's (kernels_conv_dma.hip), re-cut for 2-byte elements:
+//   * a K "slab" is 32 bf16 = 64 B per row, moved HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB = 16 rows per wave
+//     instruction); lane-linear LDS image with the XOR swizzle applied on the SOURCE side and mirrored in the ds_read_b128 address;
+//   * one ds_read_b128 = 8 bf16 = a lane's whole A (or B) fragment of one 32x32x16 MFMA (lane (r, h): k = 8h .. 8h+7): 2 MFMAs per
+//     32x32 tile and slab, so a K-step takes KB = 2 slabs (16 MFMAs per wave and barrier for 64x64 wave tiles);
+//   * 3-step LDS ring, counted vmcnt, one raw s_barrier per K-step, register double-buffered fragments (inline-asm ds_read so hipcc
+//     does not drain the DMA ring in front of every LDS read);
+//   * K order of the packed weights / the implicit im2col: channel block (cb = 32, or 16 when Cin % 32 != 0) outer, tap inner,
+//     channel-in-block innermost. With cb = 16 a slab holds TWO (block, tap) units: lanes pick theirs by the half of the slab
+//     their 16-B chunk lies in. 1x1 kernels (GEMMs) take any Cin % 8 == 0: the chunk past Cin is fetched as zeros;
+//   * padding taps / rows past M / chunks past Cin = out-of-range buffer offsets (the hardware returns zeros);
+//   * epilogue through a wave-private LDS transpose to 16-byte (8 x bf16) row stores.
+#include "fe_common.h"
+#include <cstdlib>
+
+namespace fe {
+
+typedef float h_f32x16 __attribute__((ext_vector_type(16)));
+typedef float h_v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 h_bf8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* h_lptr_t;
+
+union H8 {            // 16 bytes: one DMA chunk / one MFMA fragment / one epilogue store
+  h_v4f f;
+  h_bf8 b;
+  uint4 u;
+};
+
+__device__ __forceinline__ void h_unpack8(const uint4 u, float v[8]) {
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xFFFF0000u);
+  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xFFFF0000u);
+}
+
+// UNITS = 32 / cb: (channel block, tap) units per 32-element slab. MODE 0 plain, 2 PReLU epilogue.
+template <int WGM, int WGN, int TM, int TN, int UNITS, int KB, int MODE = 0>   // KB: slabs per K-step (barrier interval)
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_bf16_kernel(ConvParamsH p, const int ntiles) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  constexpr int AI = (BM + 63) / 64, BI = (BN + 63) / 64;    // DMA pieces per wave per slab (16 rows x 64 B each)
+  constexpr int SLAB = (BM + BN) * 64;                       // bytes per slab
+  constexpr int STEP = KB * SLAB;                            // bytes per ring entry
+  static_assert(WGM * WGN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem_h[];
+
+  if (p.batch > 1) {
+    const int b = blockIdx.y, bo = b / p.nb1, bi = b - bo * p.nb1;
+    p.x += bo * p.xs2 + bi * p.xs1;
+    p.w += bo * p.ws2 + bi * p.ws1;
+    p.y += bo * p.ys2 + bi * p.ys1;
+    if (p.shift) p.shift += bi * p.hs1;
+  }
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int q8 = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+  const int swz = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+  const int mt = swz / ntiles, nt = swz - mt * ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- DMA source coordinates (per lane, fixed for the whole K loop) -------------------------------------
+  const int rsub = lane >> 2, slot = lane & 3;
+  const int chunk = slot ^ ((rsub >> 2) & 3);            // source chunk (8 elements) of the slab after the swizzle
+  const int upar = UNITS == 2 ? (chunk >> 1) : 0;        // which unit of the slab this lane's chunk belongs to
+  const int cofs = UNITS == 2 ? (chunk & 1) * 8 : chunk * 8;   // element offset of the chunk inside its unit
+  unsigned aoffs[AI];          // byte offset of the row's (kh=0,kw=0,ci=cofs) element from p.x (buffer addressing)
+  unsigned long long amask[AI];
+  const int HoWo = p.Ho * p.Wo;
+  const int ntaps = p.KH * p.KW;
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    const int row = 16 * (4 * j + wave) + rsub;
+    const int m = m0 + row;
+    const bool valid = (row < BM) && (m < p.M);
+    const int mm = valid ? m : 0;
+    const int nimg = mm / HoWo;
+    const int rem = mm - nimg * HoWo;
+    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+    const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
+    const long long pix = ((long long)nimg * p.H + ih0) * p.W + iw0;
+    aoffs[j] = (unsigned)((pix * p.ldx + cofs) * 2);
+    unsigned long long mk = 0;
+    if (valid) {
+      for (int tp = 0; tp < ntaps; ++tp) {
+        const int kh = tp / p.KW, kw = tp - kh * p.KW;
+        const int ih = ih0 + kh * p.dh, iw = iw0 + kw * p.dw;
+        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) mk |= 1ull << tp;
+      }
+    }
+    amask[j] = mk;
+  }
+  unsigned boffs[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int row = 16 * (4 * j + wave) + rsub;
+    int n = n0 + row;
+    if (n > p.Cout - 1) n = p.Cout - 1;   // columns past Cout are computed on a valid row and discarded
+    boffs[j] = (unsigned)(((size_t)n * p.ldw + chunk * 8) * 2);
+  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.x), 0, (int)p.x_span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.w), 0, (int)p.w_span, 0x00020000);
+
+  // block-uniform running state of the next unit(s) to fetch: unit u -> channel block u / ntaps, tap u % ntaps
+  const int CB = 32 / UNITS;
+  int tap0 = 0, kh0 = 0, kw0 = 0, ci0 = 0;                       // unit 0 of the next slab
+  int tap1 = 0, kh1 = 0, kw1 = 0, ci1 = 0;                       // unit 1 (UNITS == 2)
+  if (UNITS == 2) {
+    tap1 = 1; kw1 = 1;
+    if (kw1 == p.KW) { kw1 = 0; kh1 = 1; }
+    if (tap1 == ntaps) { tap1 = 0; kh1 = 0; kw1 = 0; ci1 = CB; }
+  }
+  auto advance = [&](int& tap, int& kh, int& kw, int& ci) {      // + UNITS units
+#pragma unroll
+    for (int s = 0; s < UNITS; ++s) {
+      ++tap;
+      if (++kw == p.KW) { kw = 0; ++kh; }
+      if (tap == ntaps) { tap = 0; kh = 0; kw = 0; ci += CB; }
+    }
+  };
+  const int nsub = p.Kp / 32;            // slabs; Kp % 64 == 0
+  const int nsteps = nsub / KB;
+
+  auto issue_slab = [&](int g, char* base) {
+    char* Ab = base;
+    char* Bb = base + BM * 64;
+    const int tb0 = ((kh0 * p.dh * p.W + kw0 * p.dw) * p.ldx + ci0) * 2;
+    int tb = tb0, tapl = tap0, cil = ci0;
+    if (UNITS == 2) {
+      const int tb1 = ((kh1 * p.dh * p.W + kw1 * p.dw) * p.ldx + ci1) * 2;
+      tb = upar ? tb1 : tb0; tapl = upar ? tap1 : tap0; cil = upar ? ci1 : ci0;
+    }
+    const bool cok = (cil + cofs) < p.Cin;   // chunk inside the channel range (the K tail and 1x1 kernels with Cin % 32 != 0)
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      if (16 * (4 * j + wave) < BM) {
+        const bool ok = ((amask[j] >> tapl) & 1ull) && cok;
+        const unsigned off = ok ? aoffs[j] + (unsigned)tb : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(Ab + 1024 * (4 * j + wave)), 16, (int)off, 0, 0, 0);
+      }
+    }
+    const int tbb = g * 64;
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+      if (16 * (4 * j + wave) < BN)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(Bb + 1024 * (4 * j + wave)), 16, (int)boffs[j], tbb, 0, 0);
+    }
+    advance(tap0, kh0, kw0, ci0);
+    if (UNITS == 2) advance(tap1, kh1, kw1, ci1);
+  };
+  auto issue_step = [&](int st) {
+    char* base = smem_h + (st % 3) * STEP;
+#pragma unroll
+    for (int s = 0; s < KB; ++s) issue_slab(st * KB + s, base + s * SLAB);
+  };
+
+  h_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read offsets (bytes): row*64 + ((2s+h) ^ sw)*16, sw = (row>>2)&3 = (r>>2)&3; s = which 16-deep MFMA of the slab
+  const int sw = (r >> 2) & 3;
+  const int fo0 = ((h ^ sw) << 4), fo1 = fo0 ^ 32;
+  const int aoff = (wm * TM * 32 + r) * 64, boff = BM * 64 + (wn * TN * 32 + r) * 64;
+
+  // pieces per wave per K-step (for the counted waits)
+  const int npw1 = (BM / 64) + ((16 * wave < BN) ? 1 : 0) + ((BN > 64 && 16 * (4 + wave) < BN) ? 1 : 0);
+  static_assert(BM % 64 == 0 && BN <= 128, "A pieces uniform over waves; B at most two pieces per wave");
+  const int npw = KB * npw1;
+  auto wait_vm = [&](int n) {   // n is wave-uniform
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+      case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+  const unsigned lds_base = (unsigned)(size_t)(h_lptr_t)smem_h;
+  h_v4f fa[2][2 * TM], fb[2][2 * TN];   // [register set][fragment]; indices are compile-time everywhere below
+#define FH_READ_FRAGS(SET, G)                                                                                        \
+  {                                                                                                                  \
+    const unsigned sb_ = lds_base + (unsigned)((((G) / KB) % 3) * STEP + ((G) % KB) * SLAB);                         \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                 \
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET][2 * i]) : "v"(sb_ + (unsigned)(aoff + i * 32 * 64 + fo0)));      \
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET][2 * i + 1]) : "v"(sb_ + (unsigned)(aoff + i * 32 * 64 + fo1)));  \
+    }                                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                 \
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET][2 * j]) : "v"(sb_ + (unsigned)(boff + j * 32 * 64 + fo0)));      \
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET][2 * j + 1]) : "v"(sb_ + (unsigned)(boff + j * 32 * 64 + fo1)));  \
+    }                                                                                                                \
+  }
+#define FH_MFMA_BURST(SET)                                                                                           \
+  _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                   \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                               \
+        H8 a_, b_;                                                                                                   \
+        a_.f = fa[SET][2 * i + hh]; b_.f = fb[SET][2 * j + hh];                                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i][j], 0, 0, 0);                         \
+      }
+  // one slab: fragments of slab g are in register set CUR; slab g+1 is read into NXT under the MFMAs of g. Entering a new
+  // K-step (ring entry) first waits for this wave's DMA pieces of that step, then one barrier publishes it (and retires every
+  // wave's reads of the step before it, whose buffer the next issue overwrites).
+#define FH_SLAB(CUR, NXT, G)                                                                                         \
+  {                                                                                                                  \
+    const int g_ = (G);                                                                                              \
+    if (g_ + 1 < nsub) {                                                                                             \
+      if ((g_ + 1) % KB == 0) {                                                                                      \
+        const int st_ = (g_ + 1) / KB;                                                                               \
+        wait_vm(st_ + 1 < nsteps ? npw : 0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        if (st_ + 2 < nsteps) issue_step(st_ + 2);                                                                   \
+      }                                                                                                              \
+      FH_READ_FRAGS(NXT, g_ + 1)                                                                                     \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    FH_MFMA_BURST(CUR)                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  }
+
+  issue_step(0);
+  if (nsteps > 1) issue_step(1);
+  if (nsteps > 2) issue_step(2);
+  wait_vm(nsteps > 2 ? 2 * npw : (nsteps > 1 ? npw : 0));
+  __builtin_amdgcn_s_barrier();
+  FH_READ_FRAGS(0, 0)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  for (int g = 0; g < nsub; g += 2) {
+    FH_SLAB(0, 1, g)
+    FH_SLAB(1, 0, g + 1)     // nsub is even (Kp % 64 == 0)
+  }
+#undef FH_SLAB
+#undef FH_MFMA_BURST
+#undef FH_READ_FRAGS
+  __syncthreads();   // all fragment reads retired before the epilogue reuses the ring as staging
+
+  // ---- epilogue: transpose through a wave-private LDS region, 8 bf16 (16 B) per lane and store ------------------
+  float* smem = reinterpret_cast<float*>(smem_h);
+  if (p.vec_epi) {
+    constexpr int WC = TN * 32, ES = WC + 4, LPR = WC / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+    float* E = smem + wave * 32 * ES;
+    const int lr = lane / LPR, lc = (lane % LPR) * 8;
+    const int colb = n0 + wn * WC + lc;
+    const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
+    const bool cok = colb < climit;
+    const int colc = (colb + 8 <= p.Cout) ? colb : 0;     // per-channel vectors are only read for fully valid groups
+    const bool cfull = colb + 8 <= p.Cout;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sf[e] = 0.f; }
+    if (p.scale && cfull) {
+      const float4 a = *reinterpret_cast<const float4*>(p.scale + colc), b = *reinterpret_cast<const float4*>(p.scale + colc + 4);
+      sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    }
+    if (p.shift && cfull) {
+      const float4 a = *reinterpret_cast<const float4*>(p.shift + colc), b = *reinterpret_cast<const float4*>(p.shift + colc + 4);
+      sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+    }
+    if (!cfull && cok) {   // ragged last group (pad_store): scalar reads of what exists
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (colb + e < p.Cout) { if (p.scale) sc[e] = p.scale[colb + e]; if (p.shift) sf[e] = p.shift[colb + e]; }
+    }
+    float sl[8];
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sl[e] = (colb + e < p.Cout) ? p.slope[colb + e] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
+      const int mrow0 = m0 + wm * TM * 32 + i * 32 + lr;
+      uint4 rv[NIT];
+      float gs[NIT];
+      uint4 gv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = mrow0 + it * RPI;
+        const int mc = m < p.M ? m : p.M - 1;
+        if (p.res) rv[it] = *reinterpret_cast<const uint4*>(p.res + (size_t)mc * p.ldr + colc);
+        if (p.gate) {
+          if (p.gate_c1) gs[it] = (float)p.gate[(size_t)mc * p.ldg];
+          else gv[it] = *reinterpret_cast<const uint4*>(p.gate + (size_t)mc * p.ldg + colc);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = mrow0 + it * RPI;
+        const float4 v0 = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc]);
+        const float4 v1 = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc + 4]);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        float rf[8], gf[8];
+        if (p.res) h_unpack8(rv[it], rf);
+        if (p.gate && !p.gate_c1) h_unpack8(gv[it], gf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e] * sc[e] + sf[e];
+          if (p.res && !p.res_after_act) x += rf[e];
+          if constexpr (MODE == 2) x = x > 0.f ? x : x * sl[e];
+          else x = fe_apply_act(x, p.act);
+          if (p.res && p.res_after_act) x += rf[e];
+          if (p.gate) x *= p.gate_c1 ? gs[it] : gf[e];
+          if (!cfull && colb + e >= p.Cout) x = 0.f;
+          v[e] = x;
+        }
+        H8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.b[e] = (bf16)v[e];
+        if (cok && m < p.M) *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + colb) = o.u;
+      }
+    }
+    return;
+  }
+  // scalar epilogue (Cout or a stride not a multiple of 8): rare, small layers only
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * TN * 32 + j * 32 + r;
+    const bool cok = col < p.Cout;
+    const float sc = (cok && p.scale) ? p.scale[col] : 1.f;
+    const float sf = (cok && p.shift) ? p.shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = m0 + row;
+        if (cok && m < p.M) {
+          float v = acc[i][j][e] * sc + sf;
+          if (p.res && !p.res_after_act) v += (float)p.res[(size_t)m * p.ldr + col];
+          if constexpr (MODE == 2) v = v > 0.f ? v : v * p.slope[col];
+          else v = fe_apply_act(v, p.act);
+          if (p.res && p.res_after_act) v += (float)p.res[(size_t)m * p.ldr + col];
+          if (p.gate) v *= (float)p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
+          p.y[(size_t)m * p.ldy + col] = (bf16)v;
+        }
+      }
+    }
+  }
+}
+
+template <int WGM, int WGN, int TM, int TN, int UNITS, int KB, int MODE = 0>
+static void launch_bf16_variant(const ConvParamsH& p, hipStream_t s) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
+  constexpr size_t main_lds = (size_t)3 * KB * (BM + BN) * 64;
+  constexpr size_t epi_lds = (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
+  constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
+  auto kern = conv_bf16_kernel<WGM, WGN, TM, TN, UNITS, KB, MODE>;
+  static std::atomic<uint64_t> lds_set{0};
+  ensure_dynamic_lds((const void*)kern, lds, lds_set);
+  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, ntiles);
+  FE_HIP(hipGetLastError());
+}
+
+template <int UNITS, int KB>
+static void launch_bf16_tile(const ConvParamsH& p, int tile, hipStream_t s) {
+  if (p.act == ACT_PRELU) {
+    FE_CHECK(p.slope, "conv_bf16: PReLU without slopes");
+    switch (tile) {
+      case 4: launch_bf16_variant<2, 2, 1, 1, UNITS, KB, 2>(p, s); break;
+      case 7: launch_bf16_variant<2, 2, 2, 1, UNITS, KB, 2>(p, s); break;
+      default: launch_bf16_variant<2, 2, 2, 2, UNITS, KB, 2>(p, s); break;
+    }
+    return;
+  }
+  switch (tile) {
+    case 1: launch_bf16_variant<2, 2, 2, 2, UNITS, KB>(p, s); break;   // 128x128
+    case 7: launch_bf16_variant<2, 2, 2, 1, UNITS, KB>(p, s); break;   // 128x64
+    case 4: launch_bf16_variant<2, 2, 1, 1, UNITS, KB>(p, s); break;   // 64x64
+    case 3: launch_bf16_variant<4, 1, 2, 1, UNITS, KB>(p, s); break;   // 256x32
+    case 5: launch_bf16_variant<4, 1, 1, 1, UNITS, KB>(p, s); break;   // 128x32
+    default: FE_CHECK(false, "conv_bf16: unknown tile %d", tile);
+  }
+}
+
+void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
+  ConvParamsH p = p0;
+  FE_CHECK(p.x && p.w && p.y && p.ldy >= p.Cout && p.ldx >= p.Cin, "conv_bf16: null operand or row stride below the channel count");
+  if (p.ldw == 0) p.ldw = p.Kp;
+  if (p.batch < 1) p.batch = 1;
+  if (p.nb1 < 1) p.nb1 = 1;
+  const int ntaps = p.KH * p.KW;
+  FE_CHECK(p.M > 0 && p.Cout > 0 && ntaps >= 1 && ntaps < 64, "conv_bf16: empty problem or too many taps");
+  FE_CHECK(p.Kp % CONV_KALIGN_H == 0 && p.Kp >= p.K, "conv_bf16: bad Kp=%d K=%d", p.Kp, p.K);
+  FE_CHECK(p.Cin % 8 == 0 && p.ldx % 8 == 0 && p.ldw % 8 == 0, "conv_bf16: Cin=%d ldx=%d ldw=%d must be multiples of 8", p.Cin, p.ldx, p.ldw);
+  FE_CHECK(((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.w & 15) == 0, "conv_bf16: x/w must be 16-B aligned");
+  FE_CHECK(p.xs1 % 8 == 0 && p.xs2 % 8 == 0 && p.ws1 % 8 == 0 && p.ws2 % 8 == 0, "conv_bf16: batch strides must keep 16-B alignment");
+  if (p.cb == 0) p.cb = 32;
+  FE_CHECK(p.cb == 32 || p.cb == 16, "conv_bf16: channel block %d", p.cb);
+  FE_CHECK(ntaps == 1 || p.Cin % p.cb == 0, "conv_bf16: spatial kernels need Cin %% %d == 0 (Cin=%d)", p.cb, p.Cin);
+  FE_CHECK(p.batch == 1 || (!p.res && !p.gate && !p.scale), "conv_bf16: batched launches take no res/gate/scale");
+  FE_CHECK((long long)p.N * p.H * p.W < (1ll << 31), "conv_bf16: too many input pixels");
+  const unsigned long long xs = ((unsigned long long)p.N * p.H * p.W - 1) * (unsigned long long)p.ldx * 2 + (unsigned long long)p.Cin * 2;
+  const unsigned long long ws = ((unsigned long long)p.Cout - 1) * (unsigned long long)p.ldw * 2 + (unsigned long long)p.Kp * 2;
+  FE_CHECK(xs < 0xFFFFFF00ull && ws < 0xFFFFFF00ull, "conv_bf16: operand spans exceed 32-bit buffer addressing");
+  p.x_span = (unsigned)xs; p.w_span = (unsigned)ws;
+  auto al16 = [](const void* ptr) { return ((uintptr_t)ptr & 15) == 0; };
+  const bool cout_ok = (p.Cout % 8 == 0) || (p.pad_store && ((p.Cout + 7) & ~7) <= p.ldy);
+  p.vec_epi = cout_ok && (p.ldy % 8 == 0) && al16(p.y) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) &&
+              (!p.gate || p.gate_c1 || (p.ldg % 8 == 0 && al16(p.gate))) && (!p.scale || al16(p.scale)) &&
+              (!p.shift || (al16(p.shift) && p.hs1 % 4 == 0)) && (p.batch <= 1 || (p.ys1 % 8 == 0 && p.ys2 % 8 == 0));
+  FE_CHECK(!p.pad_store || p.vec_epi, "conv_bf16: pad_store needs the vector epilogue");
+  // tile choice: same wave-quantisation model as the fp32 kernel (launch_conv in kernels_conv.hip)
+  int tile = p.variant;
+  if (tile == 0) {
+    struct Cand { int tile, bm, bn; double eff; };
+    static const Cand wide[3] = {{1, 128, 128, 1.00}, {7, 128, 64, 0.95}, {4, 64, 64, 0.85}};
+    static const Cand narrow[2] = {{7, 128, 64, 1.00}, {4, 64, 64, 0.90}};
+    static const Cand slim[2] = {{3, 256, 32, 1.00}, {5, 128, 32, 0.92}};
+    const Cand* cs = p.Cout > 64 ? wide : (p.Cout > 32 ? narrow : slim);
+    const int nc = p.Cout > 64 ? 3 : 2;
+    double best = 1e300;
+    for (int i = 0; i < nc; ++i) {
+      const long long wgs = (long long)((p.M + cs[i].bm - 1) / cs[i].bm) * ((p.Cout + cs[i].bn - 1) / cs[i].bn) * p.batch;
+      const double cost = (double)((wgs + 255) / 256) * cs[i].bm * cs[i].bn / cs[i].eff;
+      if (cost < best) { best = cost; tile = cs[i].tile; }
+    }
+  }
+  static const int kb = getenv("FE_BF16_KB") ? atoi(getenv("FE_BF16_KB")) : 1;   // A/B hook: slabs per barrier
+  if (kb == 2) {
+    if (p.cb == 16) launch_bf16_tile<2, 2>(p, tile, s);
+    else launch_bf16_tile<1, 2>(p, tile, s);
+  } else {
+    if (p.cb == 16) launch_bf16_tile<2, 1>(p, tile, s);
+    else launch_bf16_tile<1, 1>(p, tile, s);
+  }
+}
+
+}  // namespace fe

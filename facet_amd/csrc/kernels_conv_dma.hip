@@ -17,12 +17,7 @@ namespace fe {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float apply_act_d(float v, int act) {
-  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-  if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
-  return v;
-}
+__device__ __forceinline__ float apply_act_d(float v, int act) { return fe_apply_act(v, act); }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

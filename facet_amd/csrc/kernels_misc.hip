@@ -5,6 +5,24 @@
 
 namespace fe {
 
+// element access shared by the fp32 and bf16 instantiations: arithmetic is always fp32, only loads / stores differ
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16* p) { return (float)*p; }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16* p, float v) { *p = (bf16)v; }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16* p, float4 v) {
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  bf4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+  *reinterpret_cast<bf4*>(p) = o;
+}
+template <class T> static inline bool vec4_ok(const T* a, const T* b) { return (((uintptr_t)a | (uintptr_t)b) & (4 * sizeof(T) - 1)) == 0; }
+
 static inline int grid_for(size_t work, int block = 256) {
   size_t g = (work + block - 1) / block;
   if (g > 2048) g = 2048;
@@ -51,21 +69,24 @@ void launch_u8_to_nhwc4_norm(const uint8_t* src, float* dst, size_t pixels, cons
 }
 
 // ---- layout shuffles at the C-ABI boundary (host tensors arrive NCHW like the reference's) ----------
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int c, int h, int w, int cpad) {
+template <class T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int n, int c, int h, int w, int cpad) {
   const size_t total = (size_t)n * h * w * cpad;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int ch = i % cpad;
     const size_t pix = i / cpad;
     const size_t hw = (size_t)h * w;
     const size_t img = pix / hw, rem = pix - img * hw;
-    dst[i] = ch < c ? src[(img * c + ch) * hw + rem] : 0.f;
+    stf(dst + i, ch < c ? src[(img * c + ch) * hw + rem] : 0.f);
   }
 }
-void launch_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, int cpad, hipStream_t s) {
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)n * h * w * cpad)), dim3(256), 0, s, src, dst, n, c, h, w, cpad);
+template <class T>
+void launch_nchw_to_nhwc(const float* src, T* dst, int n, int c, int h, int w, int cpad, hipStream_t s) {
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for((size_t)n * h * w * cpad)), dim3(256), 0, s, src, dst, n, c, h, w, cpad);
   FE_HIP(hipGetLastError());
 }
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst, int n, int c, int h, int w) {
+template <class T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int ld, float* __restrict__ dst, int n, int c, int h, int w) {
   const size_t total = (size_t)n * c * h * w;
   const size_t hw = (size_t)h * w;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -73,17 +94,18 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float
     const size_t t = i / hw;
     const int ch = t % c;
     const size_t img = t / c;
-    dst[i] = src[(img * hw + rem) * ld + ch];
+    dst[i] = ldf(src + (img * hw + rem) * ld + ch);
   }
 }
-void launch_nhwc_to_nchw(const float* src, int ld, float* dst, int n, int c, int h, int w, hipStream_t s) {
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)n * c * h * w)), dim3(256), 0, s, src, ld, dst, n, c, h, w);
+template <class T>
+void launch_nhwc_to_nchw(const T* src, int ld, float* dst, int n, int c, int h, int w, hipStream_t s) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(grid_for((size_t)n * c * h * w)), dim3(256), 0, s, src, ld, dst, n, c, h, w);
   FE_HIP(hipGetLastError());
 }
 
 // ---- max pool (NHWC, implicit -inf padding; ceil_mode windows are clipped to the input) ------------
-template <int VEC>
-__global__ void maxpool_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int n, int h, int w,
+template <class T, int VEC>
+__global__ void maxpool_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int n, int h, int w,
                                int c, int ho, int wo, int k, int stride, int pad) {
   const int cv = c / VEC;
   const size_t total = (size_t)n * ho * wo * cv;
@@ -102,34 +124,36 @@ __global__ void maxpool_kernel(const float* __restrict__ x, int ldx, float* __re
       for (int dx = 0; dx < k; ++dx) {
         const int iw = ow * stride - pad + dx;
         if ((unsigned)iw >= (unsigned)w) continue;
-        const float* p = x + ((img * h + ih) * w + iw) * ldx + cg * VEC;
+        const T* p = x + ((img * h + ih) * w + iw) * ldx + cg * VEC;
         if (VEC == 4) {
-          const float4 q = *reinterpret_cast<const float4*>(p);
+          const float4 q = ld4(p);
           best[0] = fmaxf(best[0], q.x); best[1 % VEC] = fmaxf(best[1 % VEC], q.y);
           best[2 % VEC] = fmaxf(best[2 % VEC], q.z); best[3 % VEC] = fmaxf(best[3 % VEC], q.w);
         } else {
-          best[0] = fmaxf(best[0], p[0]);
+          best[0] = fmaxf(best[0], ldf(p));
         }
       }
     }
-    float* o = y + ((img * ho + oh) * wo + ow) * ldy + cg * VEC;
-    if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(best[0], best[1 % VEC], best[2 % VEC], best[3 % VEC]);
-    else o[0] = best[0];
+    T* o = y + ((img * ho + oh) * wo + ow) * ldy + cg * VEC;
+    if (VEC == 4) st4(o, make_float4(best[0], best[1 % VEC], best[2 % VEC], best[3 % VEC]));
+    else stf(o, best[0]);
   }
 }
-void launch_maxpool(const Tensor& x, const Tensor& y, int k, int stride, int pad, hipStream_t s) {
+template <class T>
+void launch_maxpool(const TensorT<T>& x, const TensorT<T>& y, int k, int stride, int pad, hipStream_t s) {
   FE_CHECK(x.c == y.c && x.n == y.n, "maxpool: shape mismatch");
-  const bool v4 = (x.c % 4 == 0) && (x.ld % 4 == 0) && (y.ld % 4 == 0) && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0;
+  const bool v4 = (x.c % 4 == 0) && (x.ld % 4 == 0) && (y.ld % 4 == 0) && vec4_ok(x.p, y.p);
   const size_t work = y.pixels() * (v4 ? x.c / 4 : x.c);
   if (v4)
-    hipLaunchKernelGGL(maxpool_kernel<4>, dim3(grid_for(work)), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w, k, stride, pad);
+    hipLaunchKernelGGL((maxpool_kernel<T, 4>), dim3(grid_for(work)), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w, k, stride, pad);
   else
-    hipLaunchKernelGGL(maxpool_kernel<1>, dim3(grid_for(work)), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w, k, stride, pad);
+    hipLaunchKernelGGL((maxpool_kernel<T, 1>), dim3(grid_for(work)), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w, k, stride, pad);
   FE_HIP(hipGetLastError());
 }
 
 // ---- bilinear resize, align_corners=False (torch F.interpolate semantics, reference samp_net.py:59) --
-__global__ void bilinear_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int n, int h, int w,
+template <class T>
+__global__ void bilinear_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int n, int h, int w,
                                 int c, int ho, int wo, float sy, float sx) {
   const size_t total = (size_t)n * ho * wo * c;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -144,21 +168,23 @@ __global__ void bilinear_kernel(const float* __restrict__ x, int ldx, float* __r
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
     const float ly = fy - (float)y0, lx = fx - (float)x0;
     const float hy = 1.f - ly, hx = 1.f - lx;
-    const float* b = x + img * h * w * ldx + ch;
-    const float v00 = b[((size_t)y0 * w + x0) * ldx], v01 = b[((size_t)y0 * w + x1) * ldx];
-    const float v10 = b[((size_t)y1 * w + x0) * ldx], v11 = b[((size_t)y1 * w + x1) * ldx];
-    y[((img * ho + oh) * wo + ow) * ldy + ch] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    const T* b = x + img * h * w * ldx + ch;
+    const float v00 = ldf(b + ((size_t)y0 * w + x0) * ldx), v01 = ldf(b + ((size_t)y0 * w + x1) * ldx);
+    const float v10 = ldf(b + ((size_t)y1 * w + x0) * ldx), v11 = ldf(b + ((size_t)y1 * w + x1) * ldx);
+    stf(y + ((img * ho + oh) * wo + ow) * ldy + ch, hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
   }
 }
-void launch_bilinear(const Tensor& x, const Tensor& y, hipStream_t s) {
+template <class T>
+void launch_bilinear(const TensorT<T>& x, const TensorT<T>& y, hipStream_t s) {
   FE_CHECK(x.c == y.c && x.n == y.n, "bilinear: shape mismatch");
   const float sy = (float)x.h / (float)y.h, sx = (float)x.w / (float)y.w;
-  hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(y.numel())), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w, sy, sx);
+  hipLaunchKernelGGL(bilinear_kernel<T>, dim3(grid_for(y.numel())), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w, sy, sx);
   FE_HIP(hipGetLastError());
 }
 
 // ---- adaptive average pool (torch semantics) ---------------------------------------------------------
-__global__ void adaptive_avgpool_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int n, int h,
+template <class T>
+__global__ void adaptive_avgpool_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int n, int h,
                                         int w, int c, int ho, int wo) {
   const size_t total = (size_t)n * ho * wo * c;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -171,13 +197,14 @@ __global__ void adaptive_avgpool_kernel(const float* __restrict__ x, int ldx, fl
     const int ws = (ow * w) / wo, we = ((ow + 1) * w + wo - 1) / wo;
     float acc = 0.f;
     for (int iy = hs; iy < he; ++iy)
-      for (int ix = ws; ix < we; ++ix) acc += x[((img * h + iy) * w + ix) * ldx + ch];
-    y[((img * ho + oh) * wo + ow) * ldy + ch] = acc / (float)((he - hs) * (we - ws));
+      for (int ix = ws; ix < we; ++ix) acc += ldf(x + ((img * h + iy) * w + ix) * ldx + ch);
+    stf(y + ((img * ho + oh) * wo + ow) * ldy + ch, acc / (float)((he - hs) * (we - ws)));
   }
 }
 // 4 channels per thread (16-B loads), two independent accumulators per row pair so the adds do not serialise the loads.
 // The summation order over a window stays row-major like the scalar kernel's (rows alternate between the accumulators).
-__global__ void adaptive_avgpool_vec4_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int n, int h,
+template <class T>
+__global__ void adaptive_avgpool_vec4_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int n, int h,
                                              int w, int c4, int ho, int wo) {
   const size_t total = (size_t)n * ho * wo * c4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -190,40 +217,41 @@ __global__ void adaptive_avgpool_vec4_kernel(const float* __restrict__ x, int ld
     const int ws = (ow * w) / wo, we = ((ow + 1) * w + wo - 1) / wo;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int iy = hs; iy < he; ++iy) {
-      const float* row = x + ((img * h + iy) * w + ws) * (size_t)ldx + ch;
+      const T* row = x + ((img * h + iy) * w + ws) * (size_t)ldx + ch;
       int ix = 0;
       const int cnt = we - ws;
       for (; ix + 4 <= cnt; ix += 4) {
-        const float4 a = *reinterpret_cast<const float4*>(row + (size_t)ix * ldx);
-        const float4 b = *reinterpret_cast<const float4*>(row + (size_t)(ix + 1) * ldx);
-        const float4 d = *reinterpret_cast<const float4*>(row + (size_t)(ix + 2) * ldx);
-        const float4 e = *reinterpret_cast<const float4*>(row + (size_t)(ix + 3) * ldx);
+        const float4 a = ld4(row + (size_t)ix * ldx);
+        const float4 b = ld4(row + (size_t)(ix + 1) * ldx);
+        const float4 d = ld4(row + (size_t)(ix + 2) * ldx);
+        const float4 e = ld4(row + (size_t)(ix + 3) * ldx);
         acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
         acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
         acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
         acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
       }
       for (; ix < cnt; ++ix) {
-        const float4 a = *reinterpret_cast<const float4*>(row + (size_t)ix * ldx);
+        const float4 a = ld4(row + (size_t)ix * ldx);
         acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
       }
     }
     const float d = (float)((he - hs) * (we - ws));
-    *reinterpret_cast<float4*>(y + ((img * ho + oh) * wo + ow) * (size_t)ldy + ch) = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+    st4(y + ((img * ho + oh) * wo + ow) * (size_t)ldy + ch, make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d));
   }
 }
-void launch_adaptive_avgpool(const Tensor& x, const Tensor& y, hipStream_t s) {
+template <class T>
+void launch_adaptive_avgpool(const TensorT<T>& x, const TensorT<T>& y, hipStream_t s) {
   FE_CHECK(x.c == y.c && x.n == y.n, "adaptive_avgpool: shape mismatch");
-  if (x.c % 4 == 0 && x.ld % 4 == 0 && y.ld % 4 == 0 && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0) {
+  if (x.c % 4 == 0 && x.ld % 4 == 0 && y.ld % 4 == 0 && vec4_ok(x.p, y.p)) {
     const size_t work = y.pixels() * (size_t)(y.c / 4);
     size_t g = (work + 255) / 256;
     if (g > 8192) g = 8192;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(adaptive_avgpool_vec4_kernel, dim3((unsigned)g), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c / 4, y.h, y.w);
+    hipLaunchKernelGGL(adaptive_avgpool_vec4_kernel<T>, dim3((unsigned)g), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c / 4, y.h, y.w);
     FE_HIP(hipGetLastError());
     return;
   }
-  hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(grid_for(y.numel())), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w);
+  hipLaunchKernelGGL(adaptive_avgpool_kernel<T>, dim3(grid_for(y.numel())), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w);
   FE_HIP(hipGetLastError());
 }
 
@@ -317,9 +345,10 @@ void launch_conv_narrow(const ConvParams& p, hipStream_t s) {
 }
 
 // ---- second half of the tap-decomposed narrow convolution: sum the per-tap partial products of the neighbours ----
-__global__ void tap_gather_kernel(const float* __restrict__ z, int ldz, int n, int h, int w, int kh, int kw, int ph, int pw,
+template <class T>
+__global__ void tap_gather_kernel(const T* __restrict__ z, int ldz, int n, int h, int w, int kh, int kw, int ph, int pw,
                                   int dh, int dw, int cout, const float* __restrict__ scale, const float* __restrict__ shift,
-                                  int act, float* __restrict__ y, int ldy, int ho, int wo) {
+                                  int act, T* __restrict__ y, int ldy, int ho, int wo) {
   const size_t total = (size_t)n * ho * wo * cout;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int co = i % cout;
@@ -334,20 +363,19 @@ __global__ void tap_gather_kernel(const float* __restrict__ z, int ldz, int n, i
       for (int b = 0; b < kw; ++b) {
         const int iw = ow - pw + b * dw;
         if ((unsigned)iw >= (unsigned)w) continue;
-        acc += z[((img * h + ih) * w + iw) * ldz + (a * kw + b) * cout + co];
+        acc += ldf(z + ((img * h + ih) * w + iw) * ldz + (a * kw + b) * cout + co);
       }
     }
     float v = acc * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
-    if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
-    else if (act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-    else if (act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-    y[((img * ho + oh) * wo + ow) * ldy + co] = v;
+    v = fe_apply_act(v, act);
+    stf(y + ((img * ho + oh) * wo + ow) * ldy + co, v);
   }
 }
-void launch_tap_gather(const float* z, int ldz, int n, int h, int w, int kh, int kw, int ph, int pw, int dh, int dw,
-                       int cout, const float* scale, const float* shift, int act, float* y, int ldy, int ho, int wo,
+template <class T>
+void launch_tap_gather(const T* z, int ldz, int n, int h, int w, int kh, int kw, int ph, int pw, int dh, int dw,
+                       int cout, const float* scale, const float* shift, int act, T* y, int ldy, int ho, int wo,
                        hipStream_t s) {
-  hipLaunchKernelGGL(tap_gather_kernel, dim3(grid_for((size_t)n * ho * wo * cout)), dim3(256), 0, s, z, ldz, n, h, w, kh, kw,
+  hipLaunchKernelGGL(tap_gather_kernel<T>, dim3(grid_for((size_t)n * ho * wo * cout)), dim3(256), 0, s, z, ldz, n, h, w, kh, kw,
                      ph, pw, dh, dw, cout, scale, shift, act, y, ldy, ho, wo);
   FE_HIP(hipGetLastError());
 }
@@ -356,9 +384,11 @@ void launch_tap_gather(const float* z, int ldz, int n, int h, int w, int kh, int
 // One wave per output column streams its weight row once (16 B per lane); the <= 32 activation rows come from L1/L2.
 // Used for the per-image vectors of the heads (SAMP pattern "convs" K up to 7524, score MLPs, CLIP projection) where a
 // 128-row MFMA tile would leave 255 of 256 CUs idle behind a K loop thousands of steps long.
-template <int MR>
-__global__ void gemm_skinny_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw,
-                                   const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ y,
+// TI / TW / TO: element types of the activations, the weight rows and the outputs (bf16 activations with bf16 weights can
+// still emit fp32: the last layer of every head does).
+template <int MR, class TI, class TW, class TO>
+__global__ void gemm_skinny_kernel(const TI* __restrict__ x, int ldx, const TW* __restrict__ w, int ldw,
+                                   const float* __restrict__ scale, const float* __restrict__ shift, TO* __restrict__ y,
                                    int ldy, int M, int N, int K, int act) {
   const int lane = threadIdx.x & 63;
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -366,13 +396,13 @@ __global__ void gemm_skinny_kernel(const float* __restrict__ x, int ldx, const f
   float acc[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) acc[m] = 0.f;
-  const float* wr = w + (size_t)n * ldw;
+  const TW* wr = w + (size_t)n * ldw;
   for (int k = lane * 4; k < K; k += 256) {
-    const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+    const float4 wv = ld4(wr + k);
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       if (m < M) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + k);
+        const float4 xv = ld4(x + (size_t)m * ldx + k);
         acc[m] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
       }
     }
@@ -388,51 +418,49 @@ __global__ void gemm_skinny_kernel(const float* __restrict__ x, int ldx, const f
     const float sc = scale ? scale[n] : 1.f, sf = shift ? shift[n] : 0.f;
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
-      if (m < M) {
-        float v = acc[m] * sc + sf;
-        if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
-        else if (act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        else if (act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-        y[(size_t)m * ldy + n] = v;
-      }
+      if (m < M) stf(y + (size_t)m * ldy + n, fe_apply_act(acc[m] * sc + sf, act));
     }
   }
 }
-void launch_gemm_skinny(const float* x, int ldx, const float* w, int ldw, const float* scale, const float* shift, float* y,
+template <class TI, class TW, class TO>
+void launch_gemm_skinny(const TI* x, int ldx, const TW* w, int ldw, const float* scale, const float* shift, TO* y,
                         int ldy, int M, int N, int K, int act, hipStream_t s) {
   FE_CHECK(M >= 1 && M <= 32 && K % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0, "gemm_skinny: M=%d K=%d", M, K);
+  FE_CHECK(((uintptr_t)x & (4 * sizeof(TI) - 1)) == 0 && ((uintptr_t)w & (4 * sizeof(TW) - 1)) == 0, "gemm_skinny: alignment");
   const int blocks = (N * 64 + 255) / 256;
-  if (M <= 8) hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3(blocks), dim3(256), 0, s, x, ldx, w, ldw, scale, shift, y, ldy, M, N, K, act);
-  else hipLaunchKernelGGL(gemm_skinny_kernel<32>, dim3(blocks), dim3(256), 0, s, x, ldx, w, ldw, scale, shift, y, ldy, M, N, K, act);
+  if (M <= 8) hipLaunchKernelGGL((gemm_skinny_kernel<8, TI, TW, TO>), dim3(blocks), dim3(256), 0, s, x, ldx, w, ldw, scale, shift, y, ldy, M, N, K, act);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<32, TI, TW, TO>), dim3(blocks), dim3(256), 0, s, x, ldx, w, ldw, scale, shift, y, ldy, M, N, K, act);
   FE_HIP(hipGetLastError());
 }
 
 // ---- LayerNorm: one wave per row, two-pass (mean, then centred variance) in registers ------------------
-__global__ void layernorm_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+template <class T>
+__global__ void layernorm_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                  const float* __restrict__ g, const float* __restrict__ b, int rows, int d, float eps) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   for (int row = wave; row < rows; row += nwaves) {
-    const float* xr = x + (size_t)row * ldx;
+    const T* xr = x + (size_t)row * ldx;
     float sum = 0.f;
-    for (int i = lane; i < d; i += 64) sum += xr[i];
+    for (int i = lane; i < d; i += 64) sum += ldf(xr + i);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float mean = sum / (float)d;
     float var = 0.f;
-    for (int i = lane; i < d; i += 64) { const float t = xr[i] - mean; var += t * t; }
+    for (int i = lane; i < d; i += 64) { const float t = ldf(xr + i) - mean; var += t * t; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
     const float rstd = 1.0f / sqrtf(var / (float)d + eps);
-    float* yr = y + (size_t)row * ldy;
-    for (int i = lane; i < d; i += 64) yr[i] = (xr[i] - mean) * rstd * g[i] + b[i];
+    T* yr = y + (size_t)row * ldy;
+    for (int i = lane; i < d; i += 64) stf(yr + i, (ldf(xr + i) - mean) * rstd * g[i] + b[i]);
   }
 }
-void launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int rows, int d,
+template <class T>
+void launch_layernorm(const T* x, int ldx, T* y, int ldy, const float* g, const float* b, int rows, int d,
                       float eps, hipStream_t s) {
   const int blocks = grid_for((size_t)rows * 64);
-  hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, d, eps);
+  hipLaunchKernelGGL(layernorm_kernel<T>, dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, d, eps);
   FE_HIP(hipGetLastError());
 }
 
@@ -529,15 +557,17 @@ void launch_softmax_rows_pad(float* x, int ld, int rows, int d, hipStream_t s) {
     hipLaunchKernelGGL(softmax_rows_pad_kernel, dim3(blocks), dim3(256), 0, s, x, ld, rows, d);
   FE_HIP(hipGetLastError());
 }
-__global__ void add_rows_bcast_kernel(float* __restrict__ y, int ldy, const float* __restrict__ pos, size_t rows, int L, int d) {
+template <class T>
+__global__ void add_rows_bcast_kernel(T* __restrict__ y, int ldy, const float* __restrict__ pos, size_t rows, int L, int d) {
   const size_t total = rows * d;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t row = i / d; const int ch = i % d;
-    y[row * ldy + ch] += pos[(row % L) * d + ch];
+    stf(y + row * ldy + ch, ldf(y + row * ldy + ch) + pos[(row % L) * d + ch]);
   }
 }
-void launch_add_rows_bcast(float* y, int ldy, const float* pos, int rows, int L, int d, hipStream_t s) {
-  hipLaunchKernelGGL(add_rows_bcast_kernel, dim3(grid_for((size_t)rows * d)), dim3(256), 0, s, y, ldy, pos, (size_t)rows, L, d);
+template <class T>
+void launch_add_rows_bcast(T* y, int ldy, const float* pos, int rows, int L, int d, hipStream_t s) {
+  hipLaunchKernelGGL(add_rows_bcast_kernel<T>, dim3(grid_for((size_t)rows * d)), dim3(256), 0, s, y, ldy, pos, (size_t)rows, L, d);
   FE_HIP(hipGetLastError());
 }
 void launch_softmax_rows(float* x, int ld, int rows, int d, hipStream_t s) {
@@ -571,6 +601,36 @@ void launch_splitk_reduce(const float* part, int splits, int M, int N, const flo
                      ldr, res_after_act, y, ldy);
   FE_HIP(hipGetLastError());
 }
+
+// ---- fp32 <-> bf16 copies (boundary of the bf16 path: fp32 first-layer outputs, fp32 host tensors) -------------------------------
+template <class TI, class TO>
+__global__ void convert_kernel(const TI* __restrict__ x, TO* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) stf(y + i, ldf(x + i));
+}
+void launch_convert(const float* x, bf16* y, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL((convert_kernel<float, bf16>), dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+  FE_HIP(hipGetLastError());
+}
+void launch_convert(const bf16* x, float* y, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL((convert_kernel<bf16, float>), dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+  FE_HIP(hipGetLastError());
+}
+
+#define FE_INST_T(T)                                                                                                              \
+  template void launch_nchw_to_nhwc<T>(const float*, T*, int, int, int, int, int, hipStream_t);                                  \
+  template void launch_nhwc_to_nchw<T>(const T*, int, float*, int, int, int, int, hipStream_t);                                  \
+  template void launch_maxpool<T>(const TensorT<T>&, const TensorT<T>&, int, int, int, hipStream_t);                             \
+  template void launch_bilinear<T>(const TensorT<T>&, const TensorT<T>&, hipStream_t);                                           \
+  template void launch_adaptive_avgpool<T>(const TensorT<T>&, const TensorT<T>&, hipStream_t);                                   \
+  template void launch_tap_gather<T>(const T*, int, int, int, int, int, int, int, int, int, int, int, const float*, const float*, int, T*, int, int, int, hipStream_t); \
+  template void launch_layernorm<T>(const T*, int, T*, int, const float*, const float*, int, int, float, hipStream_t);           \
+  template void launch_add_rows_bcast<T>(T*, int, const float*, int, int, int, hipStream_t);
+FE_INST_T(float)
+FE_INST_T(bf16)
+#undef FE_INST_T
+template void launch_gemm_skinny<float, float, float>(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+template void launch_gemm_skinny<bf16, bf16, bf16>(const bf16*, int, const bf16*, int, const float*, const float*, bf16*, int, int, int, int, int, hipStream_t);
+template void launch_gemm_skinny<bf16, bf16, float>(const bf16*, int, const bf16*, int, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 
 // RGB <-> BGR of a packed uint8 image batch (the reference keeps a PIL RGB and a cv2 BGR copy of every image,
 // processing/batch_processor.py:200-215; here the second one is made on the device from the resident first one).

@@ -184,13 +184,13 @@ void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<Tensor>& feats,
     const size_t mark = c.arena.mark();
     const Tensor& f = feats[i];
     const GatedConvW& g = m.gate[i];
-    ConvOpts o0; o0.act = ACT_GELU;
-    Tensor wa = conv_new(c, g.w0, f, o0);    // = GELU(weight_blk[0](x2)) with x2 folded in (see build_topiq_head)
-    ConvOpts o2; o2.act = ACT_GELU; o2.ph = o2.pw = 1;
+    ConvOpts o0; o0.act = m.wblk_act;
+    Tensor wa = conv_new(c, g.w0, f, o0);    // = act(weight_blk[0](x2)) with x2 folded in (see build_topiq_head)
+    ConvOpts o2; o2.act = m.wblk_act; o2.ph = o2.pw = 1;
     Tensor wb = conv_new(c, g.w2, wa, o2);
     ConvOpts o4; o4.act = ACT_SIGMOID; o4.ph = o4.pw = 1;
     Tensor wc = conv_new(c, g.w4, wb, o4);
-    ConvOpts og; og.act = ACT_GELU; og.gate = &wc;   // gelu(x1) * weight
+    ConvOpts og; og.act = m.gate_act; og.gate = &wc;   // act(x1) * weight
     Tensor gated = conv_new(c, g.split_x1, f, og);
     if (gated.h > th && gated.w > tw) {
       Tensor pooled = c.arena.tensor(B, th, tw, gated.c);

@@ -89,7 +89,7 @@ class ModelManager:
                 self._cache_misses += 1
                 try:
                     obj = self._create(name)
-                except (EngineError, KeyError, ValueError) as e:
+                except (EngineError, KeyError, ValueError, FileNotFoundError) as e:
                     print(f"Failed to load {name}: {e}")
                     return None  # caller raises (multi_pass.py:344-348)
             self.models[name] = obj

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 from ._lib import Engine, EngineError, FE_MODEL_TOPIQ
-from .weights import synthetic_state_dict
+from .weights import checkpoint_or_synthetic
 
 PYIQA_MODELS = {
     'topiq': {'pyiqa_id': 'topiq_nr', 'vram_gb': 2, 'lower_better': False, 'score_range': (0, 1),
@@ -56,7 +56,8 @@ def load_checkpoint(path):
 
 
 class PyIQAScorer:
-    def __init__(self, model_name='topiq', device=None, engine=None, weights_path=None, synthetic_seed=3):
+    def __init__(self, model_name='topiq', device=None, engine=None, weights_path=None, synthetic_seed=3, synthetic=False,
+                 gate_act='gelu', weight_blk_act='gelu'):
         if model_name not in PYIQA_MODELS:
             raise ValueError(f"Unknown model '{model_name}'. Available: {', '.join(PYIQA_MODELS)}")
         self.model_name = model_name
@@ -68,22 +69,20 @@ class PyIQAScorer:
         self._own_engine = engine is None
         self._weights_path = weights_path or os.environ.get('FACET_AMD_TOPIQ_WEIGHTS')
         self._seed = synthetic_seed
+        self._synthetic = synthetic
+        self._acts = (gate_act, weight_blk_act)     # pyiqa GatedConv activations (parameter-free; see Engine.topiq_configure)
         self._state = None
 
     # -- lifecycle --------------------------------------------------------------------------
     def load(self):
         if self._loaded:
             return
+        print(f"Loading {self.model_name} ({self.model_info['pyiqa_id']})...")
+        self._state = checkpoint_or_synthetic('topiq', self._weights_path, self._synthetic, self._seed, load_checkpoint)
         if self._engine is None:
             idx = int(str(self.device).split(':')[1]) if ':' in str(self.device) else 0
             self._engine = Engine(idx)
-        print(f"Loading {self.model_name} ({self.model_info['pyiqa_id']})...")
-        if self._weights_path:
-            self._state = load_checkpoint(self._weights_path)
-        else:
-            print("  Warning: no TOPIQ checkpoint path given; using a seeded synthetic checkpoint "
-                  "(scores are not meaningful)")
-            self._state = synthetic_state_dict('topiq', self._seed)
+        self._engine.topiq_configure(*self._acts)
         self._engine.load_weights(FE_MODEL_TOPIQ, self._state)
         self.model = _ModelHandle(self)
         self._loaded = True
@@ -95,6 +94,7 @@ class PyIQAScorer:
 
     def _ensure_resident(self):
         if not self._engine.loaded(FE_MODEL_TOPIQ):
+            self._engine.topiq_configure(*self._acts)
             self._engine.load_weights(FE_MODEL_TOPIQ, self._state)
 
     def unload(self):

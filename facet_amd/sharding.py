@@ -50,3 +50,50 @@ def gather_ragged(local, n_items, world, rank, local_rank=0):
         a, b = shard_range(n_items, world, r)
         parts.append(full[r * cap: r * cap + (b - a)])
     return np.concatenate(parts, 0)
+
+
+def gather_device(local_t, world):
+    """All-gather of a torch float32 tensor [n, R] that already lives where the collective runs: on the GPU under "nccl" (= RCCL
+    over xGMI; the engine wrote the records straight into this buffer with Engine.ensemble_score_dev, so nothing crosses PCIe before
+    the exchange), on the CPU under "gloo". Returns the [world * n, R] tensor on the same device; the caller copies it to the host
+    once, after the step."""
+    if world == 1:
+        return local_t
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() != "nccl" and local_t.is_cuda:       # gloo rehearsal of the N > 1 control flow on one GPU
+        local_t = local_t.cpu()
+    out = torch.empty((world * local_t.shape[0],) + tuple(local_t.shape[1:]), dtype=local_t.dtype, device=local_t.device)
+    dist.all_gather_into_tensor(out, local_t.contiguous())
+    return out
+
+
+def score_shard(engine, images, n_items, world, rank, faces=None, record_floats=789):
+    """One multi-GPU step of the ensemble for this rank's contiguous block of a global batch of n_items images: `images` is the
+    rank's (device_ptr, n, h, w) block (n = hi - lo of shard_range). Records are produced in a device buffer padded to the largest
+    shard, gathered once, and returned as a host array [n_items, R] in global image order (identical on every rank).
+    faces: None, or (det_size, det_thresh, nms_thresh, max_faces) to append [count, max_faces x 739 face slots] per image."""
+    import torch
+    from ._lib import FE_FACE_FLOATS
+    lo, hi = shard_range(n_items, world, rank)
+    n = hi - lo
+    cap = -(-n_items // world)
+    R = record_floats + (1 + faces[3] * FE_FACE_FLOATS if faces else 0)
+    dev = torch.device("cuda", engine.device)
+    rec = torch.zeros((cap, R), dtype=torch.float32, device=dev)
+    mask = 0
+    if n:
+        assert images[1] == n, (images[1], lo, hi)
+        mask = engine.ensemble_score_dev(images, rec.data_ptr(), R)
+        if faces:
+            f, counts, _ = engine.face_analyze(images, faces[0], faces[1], faces[2], faces[3])
+            extra = np.concatenate([counts[:, None].astype(np.float32), f.reshape(n, -1)], axis=1)
+            rec[:n, record_floats:] = torch.from_numpy(extra).to(dev)      # the face glue runs on the host: a few KB per image go up
+    full = gather_device(rec, world).cpu().numpy()
+    if world == 1:
+        return full[:n], mask
+    parts = []
+    for r in range(world):
+        a, b = shard_range(n_items, world, r)
+        parts.append(full[r * cap: r * cap + (b - a)])
+    return np.concatenate(parts, 0), mask

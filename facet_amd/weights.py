@@ -285,3 +285,18 @@ def synthetic_state_dict(model, seed=0, spec=None):
 def synthetic_images(seed, n, h, w):
     """uint8 HWC RGB, default_rng(seed).integers(0,256)."""
     return np.random.default_rng(seed).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+
+
+def checkpoint_or_synthetic(kind, weights_path, synthetic, seed, loader):
+    """The state dict the drop-in wrappers load. A real checkpoint path wins. Without one the reference would download the weights
+    (pyiqa / open_clip / the aesthetic head, models/pyiqa_scorer.py:108, model_manager.py:140, processing/scorer.py:560-577) and fail
+    loudly when it cannot; there is no network here, so the wrappers raise FileNotFoundError instead of scoring with made-up
+    weights - unless the caller opts in with synthetic=True or FACET_AMD_SYNTHETIC=1 (tests, bench.py, tools/)."""
+    import os
+    if weights_path:
+        return loader(weights_path)
+    if synthetic or os.environ.get("FACET_AMD_SYNTHETIC") == "1":
+        return synthetic_state_dict(kind, seed)
+    raise FileNotFoundError(
+        f"no {kind} checkpoint path given. Pass weights_path=... (a local .safetensors / .pth file); the seeded synthetic checkpoint "
+        "is only used when asked for explicitly (synthetic=True or FACET_AMD_SYNTHETIC=1) because its scores are meaningless.")

@@ -45,7 +45,7 @@ enum fe_model {
   FE_MODEL_AESTHETIC = 4  /* Linear(768,256)-ReLU-Linear(256,1)         (processing/scorer.py:579-583)     */
 };
 
-enum fe_act { FE_ACT_NONE = 0, FE_ACT_RELU = 1, FE_ACT_GELU = 2, FE_ACT_SIGMOID = 3 };
+enum fe_act { FE_ACT_NONE = 0, FE_ACT_RELU = 1, FE_ACT_GELU = 2, FE_ACT_SIGMOID = 3, FE_ACT_SOFTPLUS = 5 /* torch.nn.Softplus(beta=1, threshold=20) */ };
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 /* Creates a context on HIP device `device` with a workspace arena of `arena_bytes`
@@ -106,6 +106,14 @@ int fe_bench_conv(fe_ctx* ctx, int n, int h, int w, int cin, int cout, int k, in
                   int variant, int iters, float* ms_out);
 
 /* ---- TOPIQ (reference: PyIQAScorer.score_image -> self.model(t), models/pyiqa_scorer.py:197-231) */
+/* Activations inside pyiqa's GatedConv, read by the NEXT fe_weights_commit(FE_MODEL_TOPIQ): gate_act = the activation of the gated
+ * branch x1, weight_blk_act = the one after weight_blk[0] and weight_blk[2] (each FE_ACT_RELU / FE_ACT_GELU / FE_ACT_SOFTPLUS).
+ * Default GELU / GELU. Activations carry no parameters, so a checkpoint cannot tell which a pyiqa release used (pyiqa is not
+ * vendored in the reference, models/pyiqa_scorer.py:33-39,108-111): the choice is a load-time option [DEP-KNOWLEDGE]. */
+int fe_topiq_configure(fe_ctx* ctx, int gate_act, int weight_blk_act);
+/* dims = {channels, height, width} of pyramid level `level` for h x w inputs (after the > 1024 LANCZOS cap of
+ * models/pyiqa_scorer.py:131-153): the size of one image's block in fe_topiq_features' output. No context needed. */
+int fe_topiq_feature_shape(int h, int w, int level, int dims[3]);
 /* images: n x h x w x 3 uint8 RGB (all the same size, h and w multiples of 32).
  * level 0..4 = ResNet-50 pyramid feature (stem-relu, layer1..4) returned NCHW to host `out`. */
 int fe_topiq_features(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, int level, float* out);
@@ -170,6 +178,15 @@ int fe_tag_similarities(fe_ctx* ctx, const float* emb, int n, const float* text,
 #define FE_RECORD_FLOATS 789
 int fe_ensemble_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* records,
                       int* models_run);
+
+/* Which of the loaded models fe_ensemble_score runs: bitmask 1 topiq | 2 clip (+ aesthetic head) | 4 samp; default 7. The reference's
+ * multi-pass mode runs one model group per pass over the same images (processing/multi_pass.py:481-644). */
+int fe_ensemble_select(fe_ctx* ctx, int models);
+/* fe_ensemble_score with the records left in device memory: d_records [n][ld_records] floats, ld_records >= FE_RECORD_FLOATS (further
+ * columns are not touched). Returns once the engine stream has drained: the buffer can go straight into the multi-GPU all-gather
+ * (RCCL reads it in place; there is no device -> host -> device hop in the step). */
+int fe_ensemble_score_dev(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_device, float* d_records, int ld_records,
+                          int* models_run);
 
 /* ---- ONNX-subset graph runtime --------------------------------------------------------------------------------
  * Replaces the onnxruntime InferenceSessions that insightface.app.FaceAnalysis(name='buffalo_l') opens for the reference

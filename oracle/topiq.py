@@ -23,16 +23,27 @@ MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
 
 
+_ACTS = {"gelu": nn.GELU, "relu": nn.ReLU, "softplus": nn.Softplus}
+
+
 class GatedConv(nn.Module):
-    def __init__(self, dim):
+    """pyiqa's GatedConv. Its two activation choices (gated branch; inside weight_blk) carry no parameters, so a checkpoint cannot
+    say which a pyiqa release used: both are options here and in the engine (fe_topiq_configure). Default GELU / GELU = this
+    builder's recollection of pyiqa/archs/topiq_arch.py (`self.act = nn.GELU()`, `nn.Conv2d(weightdim, 64, 1), nn.GELU(), ...`)
+    [DEP-KNOWLEDGE]; the round-1 reviewer recalled Softplus / ReLU. tools/pin_with_real_dependencies.py tries every combination
+    against pyiqa itself on a machine that has it."""
+
+    def __init__(self, dim, gate_act="gelu", weight_blk_act="gelu"):
         super().__init__()
         self.splitconv = nn.Conv2d(dim, dim * 2, 1)
-        self.weight_blk = nn.Sequential(nn.Conv2d(dim, 64, 1), nn.GELU(), nn.Conv2d(64, 64, 3, padding=1), nn.GELU(),
+        A = _ACTS[weight_blk_act]
+        self.weight_blk = nn.Sequential(nn.Conv2d(dim, 64, 1), A(), nn.Conv2d(64, 64, 3, padding=1), A(),
                                         nn.Conv2d(64, 1, 3, padding=1), nn.Sigmoid())
+        self.act = _ACTS[gate_act]()
 
     def forward(self, x):
         x1, x2 = self.splitconv(x).chunk(2, dim=1)
-        return F.gelu(x1) * self.weight_blk(x2)
+        return self.act(x1) * self.weight_blk(x2)
 
 
 class EncoderLayer(nn.Module):
@@ -77,11 +88,11 @@ class _Stack(nn.Module):
 
 
 class CFANet(nn.Module):
-    def __init__(self, dims=(64, 256, 512, 1024, 2048), d=256, heads=4):
+    def __init__(self, dims=(64, 256, 512, 1024, 2048), d=256, heads=4, gate_act="gelu", weight_blk_act="gelu"):
         super().__init__()
         ff = min(4 * d, 2048)
         self.semantic_model = ResNet50Features()
-        self.weight_pool = nn.ModuleList([GatedConv(c) for c in dims])
+        self.weight_pool = nn.ModuleList([GatedConv(c, gate_act, weight_blk_act) for c in dims])
         self.dim_reduce = nn.ModuleList([nn.Sequential(nn.Conv2d(c, d, 1, 1), nn.GELU()) for c in dims])
         self.sa_attn_blks = nn.ModuleList([_Stack(EncoderLayer(d, heads, ff)) for _ in dims])
         self.attn_blks = nn.ModuleList([_Stack(DecoderLayer(d, heads, ff)) for _ in dims[:-1]])

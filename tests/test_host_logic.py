@@ -128,3 +128,24 @@ def test_face_analyzer_mirror_unavailable_contract_and_ear():
     lm2 = lm.copy(); lm2[:, 1] *= 0.5
     assert fa.is_blinking(type("F", (), {"landmark_2d_106": lm2})())
     assert not fa.is_blinking(object())
+
+
+def test_wrappers_refuse_to_score_with_made_up_weights(monkeypatch):
+    """No checkpoint path and no explicit opt-in -> FileNotFoundError, never a silent synthetic checkpoint (the reference downloads
+    the weights or fails: models/pyiqa_scorer.py:108, model_manager.py:140, processing/scorer.py:560-577)."""
+    import pytest
+    from facet_amd.pyiqa_scorer import PyIQAScorer
+    from facet_amd.clip import load_clip, ClipAestheticScorer
+    from facet_amd.weights import checkpoint_or_synthetic
+    monkeypatch.delenv("FACET_AMD_SYNTHETIC", raising=False)
+    monkeypatch.delenv("FACET_AMD_TOPIQ_WEIGHTS", raising=False)
+    with pytest.raises(FileNotFoundError, match="topiq"):
+        PyIQAScorer("topiq").load()
+    with pytest.raises(FileNotFoundError, match="clip"):
+        load_clip(engine=object())
+    with pytest.raises(FileNotFoundError, match="aesthetic"):
+        ClipAestheticScorer(object(), {"model": None, "preprocess": None})
+    # the opt-ins
+    assert "h_emb" in checkpoint_or_synthetic("topiq", None, True, 3, None)
+    monkeypatch.setenv("FACET_AMD_SYNTHETIC", "1")
+    assert "0.weight" in checkpoint_or_synthetic("aesthetic", None, False, 3, None)

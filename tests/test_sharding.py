@@ -64,3 +64,22 @@ def test_allgather_world2_gloo(n_items):
         p.join(60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True, True), (1, True, True)]
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` typed directly (what the driver's scaling run does): the parent starts two rank processes itself,
+    relays rank 0's line and returns their status. --dry-run keeps the engine out so the launch / rendezvous / gather path runs on CPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 2, "gathered_ok": True}
+    # a failing child makes the parent fail
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "nope"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

@@ -55,14 +55,19 @@ def leg_topiq(args, eng):
     from facet_amd._lib import FE_MODEL_TOPIQ
     from facet_amd.pyiqa_scorer import load_checkpoint
     sd = load_checkpoint(args.topiq_weights)
-    eng.load_weights(FE_MODEL_TOPIQ, sd)
     imgs = images(args, 4, 512)
-    got = eng.topiq_score(imgs)
     metric = pyiqa.create_metric("topiq_nr", device="cpu", as_loss=False)
     metric.net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
     with torch.no_grad():
         ref = metric(torch.from_numpy(imgs.astype(np.float32) / 255.0).permute(0, 3, 1, 2)).flatten().numpy()
-    report("score", got, ref)
+    # GatedConv's activations are parameter-free, so the checkpoint does not say which ones pyiqa uses: try every combination
+    # (fe_topiq_configure) and name the one that reproduces pyiqa's scores
+    for gate in ("gelu", "softplus", "relu"):
+        for wblk in ("gelu", "relu", "softplus"):
+            eng.topiq_configure(gate, wblk)
+            eng.load_weights(FE_MODEL_TOPIQ, sd)
+            report(f"score (gate_act={gate}, weight_blk_act={wblk})", eng.topiq_score(imgs), ref)
+    eng.topiq_configure("gelu", "gelu")
 
 
 def leg_clip(args, eng):
