@@ -22,6 +22,7 @@ FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC = 0, 1, 2
 FE_FACE_FLOATS = 739
 FE_STATS_DOUBLES = 264
 FILTERS = {"lanczos": 1, "bilinear": 2, "bicubic": 3}
+PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3, "softplus": 5}
 
 
@@ -45,6 +46,8 @@ SIGNATURES = {
     "fe_version": (C.c_char_p, []),
     "fe_sync": (C.c_int, [C.c_void_p]),
     "fe_set_microbatch": (C.c_int, [C.c_void_p, C.c_int]),
+    "fe_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "fe_model_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "fe_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "fe_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fe_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -186,7 +189,7 @@ def onnx_probe(onnx_bytes):
 class Engine:
     """One engine context = one GPU (one process per GPU in multi-GPU runs)."""
 
-    def __init__(self, device=0, arena_bytes=0):
+    def __init__(self, device=0, arena_bytes=0, precision="f32"):
         self.lib = load_library()
         h = C.c_void_p()
         rc = self.lib.fe_create(int(device), int(arena_bytes), C.byref(h))
@@ -194,6 +197,8 @@ class Engine:
             raise EngineError("fe_create failed: " + (self.lib.fe_last_error(None) or b"").decode())
         self.h = h
         self.device = device
+        if PRECISION[precision]:
+            self.set_precision(precision)
 
     def close(self):
         if getattr(self, "h", None):
@@ -213,6 +218,15 @@ class Engine:
     # -- misc -------------------------------------------------------------------------------
     def sync(self):
         self._ck(self.lib.fe_sync(self.h))
+
+    def set_precision(self, precision):
+        """'f32' (default, the reference's CPU numerics) or 'bf16' (BASELINE configs[3]) for the models loaded AFTER this call."""
+        self._ck(self.lib.fe_set_precision(self.h, PRECISION[precision]))
+
+    def model_precision(self, model):
+        """'f32' / 'bf16' of a loaded model, None when it is not loaded."""
+        v = self.lib.fe_model_precision(self.h, int(model))
+        return {0: "f32", 1: "bf16"}.get(v)
 
     def set_microbatch(self, n):
         self._ck(self.lib.fe_set_microbatch(self.h, int(n)))

@@ -280,6 +280,23 @@ int fe_weights_set(fe_ctx* ctx, int model, const char* name, const float* data, 
   ctx->c.staging[model].set(name, data, shape, ndim);
   FE_API_END(ctx)
 }
+int fe_set_precision(fe_ctx* ctx, int precision) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(precision == FE_PRECISION_F32 || precision == FE_PRECISION_BF16, "set_precision: %d", precision);
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  ctx->c.precision = precision;
+  FE_API_END(ctx)
+}
+int fe_model_precision(fe_ctx* ctx, int model) {
+  if (!ctx) return -1;
+  if (model == FE_MODEL_TOPIQ && ctx->c.topiq) return ctx->c.topiq->dw.prec;
+  if (model == FE_MODEL_U2NETP && ctx->c.u2netp) return ctx->c.u2netp->dw.prec;
+  if (model == FE_MODEL_SAMP && ctx->c.samp) return ctx->c.samp->dw.prec;
+  if (model == FE_MODEL_CLIP && ctx->c.clip) return ctx->c.clip->dw.prec;
+  if (model == FE_MODEL_AESTHETIC && ctx->c.aesthetic) return FE_PRECISION_F32;
+  return -1;
+}
+
 int fe_topiq_configure(fe_ctx* ctx, int gate_act, int weight_blk_act) {
   FE_API_BEGIN(ctx)
   auto ok = [](int a) { return a == FE_ACT_RELU || a == FE_ACT_GELU || a == FE_ACT_SOFTPLUS; };
@@ -298,6 +315,7 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
   WeightStore& ws = ctx->c.staging[model];
   if (model == FE_MODEL_TOPIQ) {
     auto m = std::make_unique<TopiqModel>();
+    m->dw.prec = ctx->c.precision;
     m->gate_act = ctx->c.topiq_gate_act;
     m->wblk_act = ctx->c.topiq_wblk_act;
     const int blocks[4] = {3, 4, 6, 3};
@@ -306,10 +324,12 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
     ctx->c.topiq = std::move(m);
   } else if (model == FE_MODEL_U2NETP) {
     auto m = std::make_unique<U2NetPModel>();
+    m->dw.prec = ctx->c.precision;
     build_u2netp(*m, ws);
     ctx->c.u2netp = std::move(m);
   } else if (model == FE_MODEL_CLIP) {
     auto m = std::make_unique<ClipModel>();
+    m->dw.prec = ctx->c.precision;      // the image tower; the text tower (built below, run once per vocabulary) stays fp32
     build_clip(*m, ws);
     ctx->c.clip = std::move(m);
     if (ws.has("token_embedding.weight")) {   // full CLIP checkpoint: also build the text tower
@@ -325,6 +345,7 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
     ctx->c.aesthetic = std::move(m);
   } else if (model == FE_MODEL_SAMP) {
     auto m = std::make_unique<SampModel>();
+    m->dw.prec = ctx->c.precision;
     build_sampnet(*m, ws);
     ctx->c.samp = std::move(m);
   } else {
@@ -408,7 +429,10 @@ int fe_graph_info(fe_ctx* ctx, int slot, int* n_nodes, int* n_outputs, int64_t i
   if (flags) *flags = (gs.g.head_has_sub() ? 1 : 0) | (gs.g.head_has_mul() ? 2 : 0);
   FE_API_END(ctx)
 }
-static Tensor upload_nchw(Ctx& c, const float* x, int n, int ch, int h, int w, int cpad);
+extern "C++" {
+template <class T = float>
+static TensorT<T> upload_nchw(Ctx& c, const float* x, int n, int ch, int h, int w, int cpad);
+}
 int fe_graph_run(fe_ctx* ctx, int slot, const float* x, int n, int c, int h, int w, int on_device) {
   FE_API_BEGIN(ctx)
   Ctx& C = ctx->c;
@@ -457,21 +481,27 @@ int fe_graph_output_copy(fe_ctx* ctx, int slot, int i, float* dst, size_t cap_fl
 }
 
 // ---- single ops -----------------------------------------------------------------------------------
-static Tensor upload_nchw(Ctx& c, const float* x, int n, int ch, int h, int w, int cpad) {
+extern "C++" {
+template <class T>
+static TensorT<T> upload_nchw(Ctx& c, const float* x, int n, int ch, int h, int w, int cpad) {
   const size_t elems = (size_t)n * ch * h * w;
   float* tmp = (float*)c.arena.alloc(elems * sizeof(float));
   FE_HIP(hipMemcpyAsync(tmp, x, elems * sizeof(float), hipMemcpyHostToDevice, c.stream));
-  Tensor t = c.arena.tensor(n, h, w, cpad);
+  TensorT<T> t = c.arena.tensor_t<T>(n, h, w, cpad);
   launch_nchw_to_nhwc(tmp, t.p, n, ch, h, w, cpad, c.stream);
   return t;
 }
-static void download_nchw(Ctx& c, const Tensor& t, int ch, float* y) {
+}  // extern "C++"
+extern "C++" {
+template <class T>
+static void download_nchw(Ctx& c, const TensorT<T>& t, int ch, float* y) {
   const size_t elems = (size_t)t.n * ch * t.h * t.w;
   float* tmp = (float*)c.arena.alloc(elems * sizeof(float));
   launch_nhwc_to_nchw(t.p, t.ld, tmp, t.n, ch, t.h, t.w, c.stream);
   FE_HIP(hipMemcpyAsync(y, tmp, elems * sizeof(float), hipMemcpyDeviceToHost, c.stream));
   FE_HIP(hipStreamSynchronize(c.stream));
 }
+}  // extern "C++"
 
 int fe_op_conv2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, const float* weight, int cout, int kh, int kw,
                  const float* scale, const float* shift, const float* res, int res_after_act, int stride, int pad,
@@ -482,6 +512,7 @@ int fe_op_conv2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, const 
            "bad conv arguments");
   C.arena.reset();
   DeviceWeights dw;
+  dw.prec = C.precision;      // FE_PRECISION_BF16: the same op on the bf16 kernel (inputs rounded to bf16 on upload, fp32 back)
   WeightStore ws;
   const int64_t wshape[4] = {cout, c, kh, kw};
   ws.set("w.weight", weight, wshape, 4);
@@ -489,15 +520,26 @@ int fe_op_conv2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, const 
   std::vector<float> v;
   if (scale) { v.assign(scale, scale + cout); cw.scale = dw.upload(v); }
   if (shift) { v.assign(shift, shift + cout); cw.shift = dw.upload(v); }
-  Tensor xt = upload_nchw(C, x, n, c, h, w, cw.CinPad);
-  ConvOpts o;
-  o.sh = o.sw = stride; o.ph = o.pw = pad; o.dh = o.dw = dil; o.act = act; o.res_after_act = res_after_act;
   const int ho = conv_out_dim(h, kh, stride, pad, dil), wo = conv_out_dim(w, kw, stride, pad, dil);
   FE_CHECK(ho > 0 && wo > 0, "conv output is empty");
-  Tensor rt;
-  if (res) { rt = upload_nchw(C, res, n, cout, ho, wo, cout); o.res = &rt; }
-  Tensor yt = conv_new(C, cw, xt, o);
-  download_nchw(C, yt, cout, y);
+  if (C.precision == PREC_BF16) {
+    FE_CHECK(cw.wh, "fe_op_conv2d(bf16): Cin must be a multiple of 8 (16 for spatial kernels)");
+    TensorH xt = upload_nchw<bf16>(C, x, n, c, h, w, cw.CinPadH);
+    ConvOptsT<bf16> o;
+    o.sh = o.sw = stride; o.ph = o.pw = pad; o.dh = o.dw = dil; o.act = act; o.res_after_act = res_after_act;
+    TensorH rt;
+    if (res) { rt = upload_nchw<bf16>(C, res, n, cout, ho, wo, cout); o.res = &rt; }
+    TensorH yt = conv_new(C, cw, xt, o);
+    download_nchw(C, yt, cout, y);
+  } else {
+    Tensor xt = upload_nchw(C, x, n, c, h, w, cw.CinPad);
+    ConvOpts o;
+    o.sh = o.sw = stride; o.ph = o.pw = pad; o.dh = o.dw = dil; o.act = act; o.res_after_act = res_after_act;
+    Tensor rt;
+    if (res) { rt = upload_nchw(C, res, n, cout, ho, wo, cout); o.res = &rt; }
+    Tensor yt = conv_new(C, cw, xt, o);
+    download_nchw(C, yt, cout, y);
+  }
   FE_API_END(ctx)
 }
 
@@ -607,7 +649,9 @@ static const float kImagenetStd[3] = {0.229f, 0.224f, 0.225f};
 // Runs the backbone on images [i0, i0+nb) of a device-resident u8 batch.
 // Long edge > 1024 is first reduced with PIL-exact LANCZOS to (int(w*s), int(h*s)), s = 1024/long_edge, exactly as
 // PyIQAScorer._preprocess_image does on the host (reference models/pyiqa_scorer.py:131-153).
-static void topiq_backbone_chunk(fe_ctx* ctx, const uint8_t* d_rgb, int nb, int h, int w, std::vector<Tensor>& feats) {
+extern "C++" {
+template <class T>
+static void topiq_backbone_chunk(fe_ctx* ctx, const uint8_t* d_rgb, int nb, int h, int w, std::vector<TensorT<T>>& feats) {
   Ctx& C = ctx->c;
   const int long_edge = h > w ? h : w;
   if (long_edge > 1024) {
@@ -619,8 +663,22 @@ static void topiq_backbone_chunk(fe_ctx* ctx, const uint8_t* d_rgb, int nb, int 
   }
   Tensor x = C.arena.tensor(nb, h, w, 4);
   launch_u8_to_nhwc4_norm(d_rgb, x.p, (size_t)nb * h * w, kImagenetMean, kImagenetStd, 0, C.stream);
-  resnet_forward(C, ctx->c.topiq->backbone, x, &feats);
+  resnet_forward<T>(C, ctx->c.topiq->backbone, x, &feats);
 }
+// backbone + head of one micro-batch in the precision the model was committed under; scores are fp32 either way
+static void topiq_chunk_score(fe_ctx* ctx, const uint8_t* d_in, int nb, int h, int w, float* d_scores) {
+  Ctx& C = ctx->c;
+  if (C.topiq->dw.prec == PREC_BF16) {
+    std::vector<TensorH> feats;
+    topiq_backbone_chunk<bf16>(ctx, d_in, nb, h, w, feats);
+    topiq_head_forward<bf16>(C, *C.topiq, feats, d_scores);
+  } else {
+    std::vector<Tensor> feats;
+    topiq_backbone_chunk<float>(ctx, d_in, nb, h, w, feats);
+    topiq_head_forward<float>(C, *C.topiq, feats, d_scores);
+  }
+}
+}  // extern "C++"
 
 int fe_topiq_feature_shape(int h, int w, int level, int dims[3]) {
   if (!dims || h < 32 || w < 32 || level < 0 || level > 4) return FE_ERR_INVALID;
@@ -655,11 +713,19 @@ int fe_topiq_features(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
       FE_HIP(hipMemcpyAsync(d, rgb + (size_t)i0 * img_bytes, nb * img_bytes, hipMemcpyHostToDevice, C.stream));
       d_in = d;
     }
-    std::vector<Tensor> feats;
-    topiq_backbone_chunk(ctx, d_in, nb, h, w, feats);
-    const Tensor& f = feats[level];
-    out_per_img = (size_t)f.c * f.h * f.w;
-    download_nchw(C, f, f.c, out + (size_t)i0 * out_per_img);
+    if (C.topiq->dw.prec == PREC_BF16) {
+      std::vector<TensorH> feats;
+      topiq_backbone_chunk<bf16>(ctx, d_in, nb, h, w, feats);
+      const TensorH& f = feats[level];
+      out_per_img = (size_t)f.c * f.h * f.w;
+      download_nchw(C, f, f.c, out + (size_t)i0 * out_per_img);
+    } else {
+      std::vector<Tensor> feats;
+      topiq_backbone_chunk<float>(ctx, d_in, nb, h, w, feats);
+      const Tensor& f = feats[level];
+      out_per_img = (size_t)f.c * f.h * f.w;
+      download_nchw(C, f, f.c, out + (size_t)i0 * out_per_img);
+    }
   }
   FE_API_END(ctx)
 }
@@ -678,9 +744,7 @@ int fe_topiq_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_
       const int i0 = k * ctx->microbatch, nb = st.count(k);
       C.arena.reset();
       const uint8_t* d_in = st.get(k);
-      std::vector<Tensor> feats;
-      topiq_backbone_chunk(ctx, d_in, nb, h, w, feats);
-      topiq_head_forward(C, *C.topiq, feats, d_scores + i0);
+      topiq_chunk_score(ctx, d_in, nb, h, w, d_scores + i0);
       st.done(k);
     }
     FE_HIP(hipMemcpyAsync(scores, d_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, C.stream));
@@ -690,6 +754,26 @@ int fe_topiq_score(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int on_
 }
 
 // ---- U2-Net-P + SAMP-Net ---------------------------------------------------------------------------
+extern "C++" {
+// saliency (and optionally the SAMP-Net scores) of one chunk of normalised fp32 NHWC4 crops, in the precision the models were
+// committed under. d_sal (nullable): fp32 device [n][h][w] copy of the saliency map.
+static void samp_chunk(fe_ctx* ctx, const Tensor& x, bool with_samp, float* pw, float* at, float* sd, float* d_sal) {
+  Ctx& C = ctx->c;
+  const bool half = C.u2netp->dw.prec == PREC_BF16;
+  FE_CHECK(!with_samp || (C.samp->dw.prec == PREC_BF16) == half, "u2netp and samp_net were committed under different precisions");
+  if (half) {
+    TensorH sal = C.arena.tensor_t<bf16>(x.n, x.h, x.w, 1);
+    u2netp_forward<bf16>(C, *C.u2netp, x, sal);
+    if (with_samp) sampnet_forward<bf16>(C, *C.samp, x, sal, pw, at, sd);
+    if (d_sal) launch_convert(sal.p, d_sal, sal.numel(), C.stream);
+  } else {
+    Tensor sal = C.arena.tensor(x.n, x.h, x.w, 1);
+    u2netp_forward<float>(C, *C.u2netp, x, sal);
+    if (with_samp) sampnet_forward<float>(C, *C.samp, x, sal, pw, at, sd);
+    if (d_sal) FE_HIP(hipMemcpyAsync(d_sal, sal.p, sal.numel() * sizeof(float), hipMemcpyDeviceToDevice, C.stream));
+  }
+}
+}  // extern "C++"
 // x: host fp32 NCHW [n,3,h,w], already ImageNet-normalised (what SAMPNetScorer.preprocess yields, samp_net.py:904-928)
 int fe_u2netp_saliency(fe_ctx* ctx, const float* x, int n, int h, int w, float* sal_out) {
   FE_API_BEGIN(ctx)
@@ -701,9 +785,9 @@ int fe_u2netp_saliency(fe_ctx* ctx, const float* x, int n, int h, int w, float* 
     const int nb = std::min(ctx->microbatch, n - i0);
     C.arena.reset();
     Tensor xt = upload_nchw(C, x + (size_t)i0 * per, nb, 3, h, w, 4);
-    Tensor sal = C.arena.tensor(nb, h, w, 1);
-    u2netp_forward(C, *C.u2netp, xt, sal);
-    FE_HIP(hipMemcpyAsync(sal_out + (size_t)i0 * h * w, sal.p, (size_t)nb * h * w * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+    float* d_sal = C.arena.array<float>((size_t)nb * h * w);
+    samp_chunk(ctx, xt, false, nullptr, nullptr, nullptr, d_sal);
+    FE_HIP(hipMemcpyAsync(sal_out + (size_t)i0 * h * w, d_sal, (size_t)nb * h * w * sizeof(float), hipMemcpyDeviceToHost, C.stream));
     FE_HIP(hipStreamSynchronize(C.stream));
   }
   FE_API_END(ctx)
@@ -724,11 +808,9 @@ int fe_samp_forward(fe_ctx* ctx, const float* x, int n, float* pattern_weights, 
     const int nb = std::min(ctx->microbatch, n - i0);
     C.arena.reset();
     Tensor xt = upload_nchw(C, x + (size_t)i0 * per, nb, 3, h, w, 4);
-    Tensor sal = C.arena.tensor(nb, h, w, 1);
-    u2netp_forward(C, *C.u2netp, xt, sal);
-    sampnet_forward(C, *C.samp, xt, sal, d_out + (size_t)i0 * 8, d_out + (size_t)n * 8 + (size_t)i0 * 6,
-                    d_out + (size_t)n * 14 + (size_t)i0 * 5);
-    if (sal_out) FE_HIP(hipMemcpyAsync(sal_out + (size_t)i0 * h * w, sal.p, (size_t)nb * h * w * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+    float* d_sal = sal_out ? C.arena.array<float>((size_t)nb * h * w) : nullptr;
+    samp_chunk(ctx, xt, true, d_out + (size_t)i0 * 8, d_out + (size_t)n * 8 + (size_t)i0 * 6, d_out + (size_t)n * 14 + (size_t)i0 * 5, d_sal);
+    if (sal_out) FE_HIP(hipMemcpyAsync(sal_out + (size_t)i0 * h * w, d_sal, (size_t)nb * h * w * sizeof(float), hipMemcpyDeviceToHost, C.stream));
     FE_HIP(hipStreamSynchronize(C.stream));
   }
   FE_HIP(hipMemcpyAsync(pattern_weights, d_out, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, C.stream));
@@ -768,6 +850,10 @@ static int clip_tower_chunk(const ClipModel& m, int n) {
   }
   return best;
 }
+static void clip_tower(Ctx& C, const Tensor& x, float* feat) {   // in the precision the tower was committed under
+  if (C.clip->dw.prec == PREC_BF16) clip_forward<bf16>(C, *C.clip, x, feat);
+  else clip_forward<float>(C, *C.clip, x, feat);
+}
 class ClipBatcher {
  public:
   ClipBatcher(fe_ctx* ctx, int n_total, int max_push, float* d_feat, float* d_norm, float* d_aes)
@@ -802,7 +888,7 @@ class ClipBatcher {
     const size_t mark = C.arena.mark();
     Tensor x;
     x.p = x_->clip_in; x.n = c; x.h = hw_; x.w = hw_; x.c = 4; x.ld = 4;
-    clip_forward(C, *C.clip, x, feat_ + (size_t)done_ * od_);
+    clip_tower(C, x, feat_ + (size_t)done_ * od_);
     if (norm_) l2_normalize(C, feat_ + (size_t)done_ * od_, norm_ + (size_t)done_ * od_, c, od_);
     if (aes_) aesthetic_forward(C, *C.aesthetic, feat_ + (size_t)done_ * od_, c, aes_ + done_);
     C.arena.rewind(mark);
@@ -850,9 +936,7 @@ class SampBatcher {
     const size_t mark = C.arena.mark();
     Tensor x;
     x.p = x_->samp_in; x.n = c; x.h = 224; x.w = 224; x.c = 4; x.ld = 4;
-    Tensor sal = C.arena.tensor(c, 224, 224, 1);
-    u2netp_forward(C, *C.u2netp, x, sal);
-    sampnet_forward(C, *C.samp, x, sal, pw_ + (size_t)done_ * 8, at_ + (size_t)done_ * 6, sd_ + (size_t)done_ * 5);
+    samp_chunk(x_, x, true, pw_ + (size_t)done_ * 8, at_ + (size_t)done_ * 6, sd_ + (size_t)done_ * 5, nullptr);
     C.arena.rewind(mark);
     const int left = count_ - c;
     compact_crops(x_->samp_in, per_, c, left, C.stream);
@@ -909,7 +993,7 @@ int fe_clip_encode_image(fe_ctx* ctx, const float* x, int n, int on_device, floa
     } else {
       xt = upload_nchw(C, x + (size_t)i0 * per, nb, 3, hw, hw, 4);
     }
-    clip_forward(C, *C.clip, xt, d_feat + (size_t)i0 * od);
+    clip_tower(C, xt, d_feat + (size_t)i0 * od);
     if (emb_norm) l2_normalize(C, d_feat + (size_t)i0 * od, d_norm + (size_t)i0 * od, nb, od);
     if (aesthetic_raw) aesthetic_forward(C, *C.aesthetic, d_feat + (size_t)i0 * od, nb, d_aes + i0);
   }
@@ -1125,9 +1209,7 @@ static int ensemble_run(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, in
     const uint8_t* d_in = st.get(k);
     if (do_topiq) {
       const size_t mark = C.arena.mark();
-      std::vector<Tensor> feats;
-      topiq_backbone_chunk(ctx, d_in, nb, h, w, feats);
-      topiq_head_forward(C, *C.topiq, feats, p_topiq + i0);
+      topiq_chunk_score(ctx, d_in, nb, h, w, p_topiq + i0);
       C.arena.rewind(mark);
     }
     if (do_clip) {

@@ -83,20 +83,35 @@ struct MHAW {
   int d = 0, heads = 0;
 };
 MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& prefix, int heads);
+// The layer wrappers below exist for T = float (fp32 path) and T = bf16 (models committed under PREC_BF16): same call shapes,
+// overloads / explicit instantiations in engine.hip.
 // y[B*Lq][d] = res + out_proj(softmax(q k^T / sqrt(hd)) v); q from q_in, k/v from kv_in (rows = tokens).
-void mha_forward(Ctx& c, const MHAW& m, const float* q_in, int ldq, const float* kv_in, int ldkv, int B, int Lq,
-                 int Lk, const float* res, int ldr, float* y, int ldy, bool causal = false);
+template <class T>
+void mha_forward(Ctx& c, const MHAW& m, const T* q_in, int ldq, const T* kv_in, int ldkv, int B, int Lq,
+                 int Lk, const T* res, int ldr, T* y, int ldy, bool causal = false);
 // y[M][N] = act(x[M][K] W^T + b) (+res)
 void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act,
                     const float* res = nullptr, int ldr = 0);
-inline Tensor mat_view(const float* p, int rows, int cols, int ld) {
-  Tensor t; t.p = const_cast<float*>(p); t.n = 1; t.h = 1; t.w = rows; t.c = cols; t.ld = ld; return t;
+void linear_forward(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16* y, int ldy, int act,
+                    const bf16* res = nullptr, int ldr = 0);
+// same with fp32 outputs whatever the activation type (the last layer of a head: scores / features leave the engine in fp32)
+void linear_forward_f32(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act);
+void linear_forward_f32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float* y, int ldy, int act);
+template <class T>
+inline TensorT<T> mat_view(const T* p, int rows, int cols, int ld) {
+  TensorT<T> t; t.p = const_cast<T*>(p); t.n = 1; t.h = 1; t.w = rows; t.c = cols; t.ld = ld; return t;
 }
 
 // Runs conv on views; allocates nothing. Output spatial dims must already be set on y.
 void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, const ConvOpts& o);
+void conv_forward(Ctx& c, const ConvW& w, const TensorH& x, const TensorH& y, const ConvOptsT<bf16>& o);
 // Allocates the output from the arena with the standard conv output size.
-Tensor conv_new(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o);
+template <class T>
+TensorT<T> conv_new(Ctx& c, const ConvW& w, const TensorT<T>& x, const ConvOptsT<T>& o);
+// First layer of a network: fp32 NHWC4 pixels in, activations of type T out (the 3-channel layers always run on the fp32 stem /
+// generic kernels; with T = bf16 their epilogue - or one conversion pass - hands bf16 to the rest of the network).
+template <class T>
+TensorT<T> first_conv(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o);
 inline int conv_out_dim(int in, int k, int s, int p, int d) { return (in + 2 * p - d * (k - 1) - 1) / s + 1; }
 
 // ---- ResNet (timm resnet50 features_only / torchvision resnet18 children[:-2]) -------------------
@@ -114,8 +129,9 @@ struct ResNet {
 // of reference models/samp_net.py:652-662 when `seq_names` is true (0=conv1,1=bn1,4..7=layer1..4).
 void build_resnet(ResNet& r, DeviceWeights& dw, const WeightStore& ws, const std::string& prefix,
                   bool bottleneck, const int blocks[4], bool seq_names);
-// feats (optional) receives [stem-relu, layer1..layer4]; returns layer4 output.
-Tensor resnet_forward(Ctx& c, const ResNet& r, const Tensor& x_nhwc4, std::vector<Tensor>* feats);
+// feats (optional) receives [stem-relu, layer1..layer4]; returns layer4 output. x is always the fp32 NHWC4 image tensor.
+template <class T>
+TensorT<T> resnet_forward(Ctx& c, const ResNet& r, const Tensor& x_nhwc4, std::vector<TensorT<T>>* feats);
 
 // ---- PIL-exact uint8 resampling (kernels_resize.hip) --------------------------------------------------
 enum ResizeFilter : int { FE_FILTER_LANCZOS = 1, FE_FILTER_BILINEAR = 2, FE_FILTER_BICUBIC = 3 };  // PIL's enum values
@@ -142,6 +158,7 @@ struct Ctx {
   double flops_accum = 0.0;
   double flops_saved = 0.0;   // algorithmic FLOPs NOT executed because a layer ran as Winograd (executed = flops_accum - flops_saved)
   int force_variant = 0;   // developer hook: forwarded to ConvParams.variant
+  int precision = PREC_F32;   // what the NEXT fe_weights_commit builds (fe_set_precision); each model remembers its own
   // TOPIQ GatedConv activations picked up by the next fe_weights_commit(FE_MODEL_TOPIQ) (fe_topiq_configure)
   int topiq_gate_act = ACT_GELU, topiq_wblk_act = ACT_GELU;
 
@@ -198,14 +215,17 @@ struct SampModel {
 };
 void build_u2netp(U2NetPModel& m, const WeightStore& ws);
 void build_sampnet(SampModel& m, const WeightStore& ws);
-void u2netp_forward(Ctx& c, const U2NetPModel& m, const Tensor& x_nhwc4, const Tensor& sal);
-void sampnet_forward(Ctx& c, const SampModel& m, const Tensor& x_nhwc4, const Tensor& sal, float* pw, float* attrs,
+// T = activation type (float | bf16); x_nhwc4 is always the fp32 pixel tensor, the score outputs are always fp32
+template <class T>
+void u2netp_forward(Ctx& c, const U2NetPModel& m, const Tensor& x_nhwc4, const TensorT<T>& sal);
+template <class T>
+void sampnet_forward(Ctx& c, const SampModel& m, const Tensor& x_nhwc4, const TensorT<T>& sal, float* pw, float* attrs,
                      float* dist);
 
 // ---- CLIP ViT image tower + aesthetic MLP -------------------------------------------------------------
 struct ClipBlockW { LayerNormW ln1, ln2; MHAW attn; ConvW fc, proj; };
 struct ClipModel {
-  DeviceWeights dw;
+  DeviceWeights dw;   // dw.prec = the precision this model was committed under
   ConvW patch, proj;
   float* pos = nullptr; float* cls = nullptr;
   LayerNormW ln_pre, ln_post;
@@ -228,12 +248,17 @@ void build_clip_text(ClipTextModel& m, const WeightStore& ws);
 void clip_text_forward(Ctx& c, const ClipTextModel& m, const int* tokens, const int* eot, int B, float* feat);
 void build_clip(ClipModel& m, const WeightStore& ws);
 void build_aesthetic(AestheticModel& m, const WeightStore& ws);
+template <class T>   // T: activation type of the tower; input pixels and output features are fp32 either way
 void clip_forward(Ctx& c, const ClipModel& m, const Tensor& x_nhwc4, float* feat);
 void aesthetic_forward(Ctx& c, const AestheticModel& m, const float* feat, int B, float* raw);
 void l2_normalize(Ctx& c, const float* x, float* y, int rows, int d);
 
 void build_topiq_head(TopiqModel& m, const WeightStore& ws);
 // feats: the 5 pyramid levels for nb images; scores_dev: device [nb]
-void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<Tensor>& feats, float* scores_dev);
+template <class T>
+void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<TensorT<T>>& feats, float* scores_dev);
+// fp32 view of an activation vector: the pointer itself for fp32, an arena copy for bf16
+inline const float* to_f32(Ctx&, const float* p, size_t) { return p; }
+const float* to_f32(Ctx& c, const bf16* p, size_t n);
 
 }  // namespace fe

@@ -1,6 +1,7 @@
 // Engine runtime: weight packing, conv/linear wrappers and the ResNet graphs.
 #include "engine.h"
 #include "onnx_graph.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -39,6 +40,12 @@ void DeviceWeights::release() {
   for (void* p : ptrs_) (void)hipFree(p);
   ptrs_.clear();
   bytes_ = 0;
+}
+
+const float* to_f32(Ctx& c, const bf16* p, size_t n) {
+  float* f = c.arena.array<float>(n);
+  launch_convert(p, f, n, c.stream);
+  return f;
 }
 
 Ctx::~Ctx() {
@@ -389,9 +396,96 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
   c.flops_accum += 2.0 * p.M * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : p.Cout);
 }
 
-Tensor conv_new(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o) {
-  Tensor y = c.arena.tensor(x.n, conv_out_dim(x.h, w.KH, o.sh, o.ph, o.dh), conv_out_dim(x.w, w.KW, o.sw, o.pw, o.dw), w.Cout);
+// ---- bf16 path ------------------------------------------------------------------------------------------------------
+// Every dense layer goes to the bf16 MFMA kernel directly: no Winograd (F(4x4) needs more than 8 mantissa bits, and at the bf16
+// matrix rate the 3x3 layers are bound by their HBM streams, which the transforms would multiply), no split-K.
+void conv_forward(Ctx& c, const ConvW& w, const TensorH& x, const TensorH& y, const ConvOptsT<bf16>& o) {
+  FE_CHECK(w.wh, "conv(bf16): this layer has no bf16 weights (model not committed under bf16 precision, or a 3-channel first layer)");
+  FE_CHECK(x.c == w.CinPadH, "conv(bf16): input channels %d != packed Cin %d", x.c, w.CinPadH);
+  FE_CHECK(y.c == w.Cout && y.n == x.n, "conv(bf16): output view mismatch (c=%d Cout=%d)", y.c, w.Cout);
+  FE_CHECK(y.h == conv_out_dim(x.h, w.KH, o.sh, o.ph, o.dh) && y.w == conv_out_dim(x.w, w.KW, o.sw, o.pw, o.dw),
+           "conv(bf16): output dims %dx%d inconsistent with input %dx%d", y.h, y.w, x.h, x.w);
+  FE_CHECK(y.pixels() < (1ull << 31), "conv: M too large");
+  const double flops = 2.0 * (double)y.pixels() * (double)(w.KH * w.KW * w.Cin) * (w.CoutAlg ? w.CoutAlg : w.Cout);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c.profile) {
+    FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
+    FE_HIP(hipEventRecord(e0, c.stream));
+  }
+  ConvParamsH p{};
+  p.scale = w.scale; p.shift = w.shift; p.slope = w.slope;
+  p.N = x.n; p.H = x.h; p.W = x.w; p.Cin = w.CinPadH; p.x = x.p; p.ldx = x.ld;
+  if (w.wtap_h && o.act != ACT_PRELU && o.sh == 1 && o.sw == 1 && !o.res && !o.gate && y.h == x.h && y.w == x.w) {
+    // narrow spatial conv (Cout <= 2): 1x1 conv to per-tap partials on the matrix cores + a gather-sum pass (see the fp32 path)
+    const int T = w.KH * w.KW * w.Cout, T8 = (T + 7) & ~7;
+    const size_t mark = c.arena.mark();
+    TensorH z = c.arena.tensor_t<bf16>(x.n, x.h, x.w, T8);
+    p.w = w.wtap_h; p.y = z.p; p.ldy = T8; p.scale = p.shift = p.slope = nullptr;
+    p.Ho = x.h; p.Wo = x.w; p.Cout = T8; p.KH = p.KW = 1; p.sh = p.sw = p.dh = p.dw = 1;
+    p.K = w.CinPadH; p.Kp = w.KpTH; p.M = (int)x.pixels(); p.cb = 32;
+    launch_conv_bf16(p, c.stream);
+    launch_tap_gather(z.p, T8, x.n, x.h, x.w, w.KH, w.KW, o.ph, o.pw, o.dh, o.dw, w.Cout, w.scale, w.shift, o.act, y.p, y.ld, y.h, y.w, c.stream);
+    c.arena.rewind(mark);
+  } else {
+    FE_CHECK(o.act != ACT_PRELU || w.slope, "conv: PReLU without slopes");
+    if (o.res) {
+      FE_CHECK(o.res->c == y.c && o.res->pixels() == y.pixels(), "conv: residual shape mismatch");
+      p.res = o.res->p; p.ldr = o.res->ld;
+    }
+    if (o.gate) {
+      FE_CHECK(o.gate->pixels() == y.pixels() && (o.gate->c == 1 || o.gate->c == y.c), "conv: gate shape mismatch");
+      p.gate = o.gate->p; p.ldg = o.gate->ld; p.gate_c1 = o.gate->c == 1;
+    }
+    p.w = w.wh; p.y = y.p; p.ldy = y.ld;
+    p.Ho = y.h; p.Wo = y.w; p.Cout = w.Cout;
+    p.KH = w.KH; p.KW = w.KW; p.sh = o.sh; p.sw = o.sw; p.ph = o.ph; p.pw = o.pw; p.dh = o.dh; p.dw = o.dw;
+    p.K = w.KH * w.KW * w.CinPadH; p.Kp = w.KpH; p.M = (int)y.pixels(); p.cb = w.cb;
+    p.act = o.act; p.res_after_act = o.res_after_act;
+    p.variant = c.force_variant;
+    launch_conv_bf16(p, c.stream);
+  }
+  if (c.profile) {
+    FE_HIP(hipEventRecord(e1, c.stream));
+    FE_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FE_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    char nm[128];
+    snprintf(nm, sizeof nm, "bf16 conv%dx%d s%d d%d M=%d K=%d N=%d", w.KH, w.KW, o.sh, o.dh, (int)y.pixels(), w.KH * w.KW * w.Cin, w.Cout);
+    const double bytes = 2.0 * ((double)x.pixels() * x.c + (double)y.pixels() * y.c * (o.res ? 2 : 1) + (double)w.Cout * w.KpH);
+    c.timings.push_back({nm, flops, bytes, ms});
+  }
+  c.flops_accum += flops;
+}
+
+template <class T>
+TensorT<T> conv_new(Ctx& c, const ConvW& w, const TensorT<T>& x, const ConvOptsT<T>& o) {
+  TensorT<T> y = c.arena.tensor_t<T>(x.n, conv_out_dim(x.h, w.KH, o.sh, o.ph, o.dh), conv_out_dim(x.w, w.KW, o.sw, o.pw, o.dw), w.Cout);
   conv_forward(c, w, x, y, o);
+  return y;
+}
+template Tensor conv_new<float>(Ctx&, const ConvW&, const Tensor&, const ConvOpts&);
+template TensorH conv_new<bf16>(Ctx&, const ConvW&, const TensorH&, const ConvOptsT<bf16>&);
+
+template <>
+Tensor first_conv<float>(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o) { return conv_new(c, w, x, o); }
+template <>
+TensorH first_conv<bf16>(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o) {
+  const int ho = conv_out_dim(x.h, w.KH, o.sh, o.ph, o.dh), wo = conv_out_dim(x.w, w.KW, o.sw, o.pw, o.dw);
+  TensorH y = c.arena.tensor_t<bf16>(x.n, ho, wo, w.Cout);
+  static const bool no_stem = getenv("FE_NO_STEM") != nullptr;
+  const bool stem = w.wstem && !no_stem && o.sh == o.sw && o.ph == w.KH / 2 && o.pw == w.KW / 2 && o.dh == 1 && o.dw == 1 && !o.res && !o.gate &&
+                    (o.act == ACT_NONE || o.act == ACT_RELU || o.act == ACT_PRELU);
+  if (stem && launch_stem(x.p, x.ld, x.n, x.h, x.w, w.wstem, w.scale, w.shift, w.slope, w.Cout, w.KH, o.sh,
+                          o.act == ACT_RELU ? 1 : (o.act == ACT_PRELU ? 2 : 0), y.p, y.ld, ho, wo, c.stream)) {
+    c.flops_accum += 2.0 * (double)y.pixels() * (double)(w.KH * w.KW * w.Cin) * w.Cout;
+    return y;
+  }
+  // shapes the stem kernel does not take: the fp32 kernel, then one conversion pass
+  const size_t mark = c.arena.mark();
+  Tensor yf = conv_new(c, w, x, o);
+  launch_convert(yf.p, y.p, y.numel(), c.stream);
+  (void)mark;   // yf stays allocated until the caller's next rewind: y was taken from the arena before it
   return y;
 }
 
@@ -423,32 +517,33 @@ void build_resnet(ResNet& r, DeviceWeights& dw, const WeightStore& ws, const std
   }
 }
 
-Tensor resnet_forward(Ctx& c, const ResNet& r, const Tensor& x, std::vector<Tensor>* feats) {
+template <class T>
+TensorT<T> resnet_forward(Ctx& c, const ResNet& r, const Tensor& x, std::vector<TensorT<T>>* feats) {
   ConvOpts so; so.sh = so.sw = 2; so.ph = so.pw = 3; so.act = ACT_RELU;
-  Tensor t = conv_new(c, r.stem, x, so);
+  TensorT<T> t = first_conv<T>(c, r.stem, x, so);
   if (feats) feats->push_back(t);
-  Tensor p = c.arena.tensor(t.n, conv_out_dim(t.h, 3, 2, 1, 1), conv_out_dim(t.w, 3, 2, 1, 1), t.c);
+  TensorT<T> p = c.arena.tensor_t<T>(t.n, conv_out_dim(t.h, 3, 2, 1, 1), conv_out_dim(t.w, 3, 2, 1, 1), t.c);
   launch_maxpool(t, p, 3, 2, 1, c.stream);
   t = p;
   for (size_t li = 0; li < r.layers.size(); ++li) {
     for (const ResBlock& b : r.layers[li]) {
-      Tensor idt = t;
+      TensorT<T> idt = t;
       if (b.has_down) {
-        ConvOpts d; d.sh = d.sw = b.stride;
+        ConvOptsT<T> d; d.sh = d.sw = b.stride;
         idt = conv_new(c, b.down, t, d);
       }
       if (b.bottleneck) {
         // torchvision v1.5 / timm: stride sits on the 3x3 (conv2)
-        ConvOpts o1; o1.act = ACT_RELU;
-        Tensor a = conv_new(c, b.c1, t, o1);
-        ConvOpts o2; o2.sh = o2.sw = b.stride; o2.ph = o2.pw = 1; o2.act = ACT_RELU;
-        Tensor bb = conv_new(c, b.c2, a, o2);
-        ConvOpts o3; o3.act = ACT_RELU; o3.res = &idt;
+        ConvOptsT<T> o1; o1.act = ACT_RELU;
+        TensorT<T> a = conv_new(c, b.c1, t, o1);
+        ConvOptsT<T> o2; o2.sh = o2.sw = b.stride; o2.ph = o2.pw = 1; o2.act = ACT_RELU;
+        TensorT<T> bb = conv_new(c, b.c2, a, o2);
+        ConvOptsT<T> o3; o3.act = ACT_RELU; o3.res = &idt;
         t = conv_new(c, b.c3, bb, o3);
       } else {
-        ConvOpts o1; o1.sh = o1.sw = b.stride; o1.ph = o1.pw = 1; o1.act = ACT_RELU;
-        Tensor a = conv_new(c, b.c1, t, o1);
-        ConvOpts o2; o2.ph = o2.pw = 1; o2.act = ACT_RELU; o2.res = &idt;
+        ConvOptsT<T> o1; o1.sh = o1.sw = b.stride; o1.ph = o1.pw = 1; o1.act = ACT_RELU;
+        TensorT<T> a = conv_new(c, b.c1, t, o1);
+        ConvOptsT<T> o2; o2.ph = o2.pw = 1; o2.act = ACT_RELU; o2.res = &idt;
         t = conv_new(c, b.c2, a, o2);
       }
     }
@@ -456,6 +551,8 @@ Tensor resnet_forward(Ctx& c, const ResNet& r, const Tensor& x, std::vector<Tens
   }
   return t;
 }
+template Tensor resnet_forward<float>(Ctx&, const ResNet&, const Tensor&, std::vector<Tensor>*);
+template TensorH resnet_forward<bf16>(Ctx&, const ResNet&, const Tensor&, std::vector<TensorH>*);
 
 }  // namespace fe
 
@@ -477,6 +574,32 @@ void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, floa
   Tensor rt;
   if (res) { rt = mat_view(res, M, w.Cout, ldr); o.res = &rt; }
   conv_forward(c, w, xt, yt, o);
+}
+void linear_forward_f32(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act) {
+  linear_forward(c, w, x, ldx, M, y, ldy, act);
+}
+
+void linear_forward(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16* y, int ldy, int act, const bf16* res, int ldr) {
+  FE_CHECK(w.wh, "linear(bf16): layer has no bf16 weights");
+  if (M <= 32 && !res && act != ACT_PRELU && ldx % 4 == 0 && ((uintptr_t)x & 7) == 0) {
+    launch_gemm_skinny(x, ldx, (const bf16*)w.wh, w.KpH, w.scale, w.shift, y, ldy, M, w.Cout, w.CinPadH, act, c.stream);
+    c.flops_accum += 2.0 * M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : w.Cout);
+    return;
+  }
+  TensorH xt = mat_view(x, M, w.CinPadH, ldx), yt = mat_view(y, M, w.Cout, ldy);
+  ConvOptsT<bf16> o; o.act = act;
+  TensorH rt;
+  if (res) { rt = mat_view(res, M, w.Cout, ldr); o.res = &rt; }
+  conv_forward(c, w, xt, yt, o);
+}
+// bf16 activations, fp32 results: the weight matrix is streamed once per block of 32 rows (heads only: M is a batch size)
+void linear_forward_f32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float* y, int ldy, int act) {
+  FE_CHECK(w.wh && act != ACT_PRELU && ldx % 4 == 0 && ((uintptr_t)x & 7) == 0, "linear_f32(bf16): unsupported layer");
+  for (int m0 = 0; m0 < M; m0 += 32) {
+    const int mb = std::min(32, M - m0);
+    launch_gemm_skinny(x + (size_t)m0 * ldx, ldx, (const bf16*)w.wh, w.KpH, w.scale, w.shift, y + (size_t)m0 * ldy, ldy, mb, w.Cout, w.CinPadH, act, c.stream);
+  }
+  c.flops_accum += 2.0 * M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : w.Cout);
 }
 
 MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& prefix, int heads) {
@@ -507,61 +630,76 @@ MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& pref
   return m;
 }
 
-static void raw_gemm(Ctx& c, ConvParams& p, double flops) {
+static void launch_gemm(const ConvParams& p, hipStream_t s) { launch_conv(p, s); }
+static void launch_gemm(const ConvParamsH& p, hipStream_t s) { launch_conv_bf16(p, s); }
+
+template <class T>
+static void raw_gemm(Ctx& c, ConvParamsT<T>& p, double flops) {
+  constexpr int kalign = sizeof(T) == 2 ? CONV_KALIGN_H : CONV_KALIGN;
+  constexpr int valign = 16 / sizeof(T);
   p.N = 1; p.H = 1; p.W = p.M; p.Ho = 1; p.Wo = p.M;
   p.KH = p.KW = 1; p.sh = p.sw = p.dh = p.dw = 1; p.ph = p.pw = 0;
-  p.Kp = (p.K + CONV_KALIGN - 1) / CONV_KALIGN * CONV_KALIGN;
+  p.Kp = (p.K + kalign - 1) / kalign * kalign;
   p.Cin = p.K;
-  FE_CHECK(p.xs1 % 4 == 0 && p.xs2 % 4 == 0 && p.ws1 % 4 == 0 && p.ws2 % 4 == 0, "raw_gemm: batch strides must keep 16-B alignment");
-  auto launch = [&]() { launch_conv(p, c.stream); };
+  FE_CHECK(p.xs1 % valign == 0 && p.xs2 % valign == 0 && p.ws1 % valign == 0 && p.ws2 % valign == 0, "raw_gemm: batch strides must keep 16-B alignment");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c.profile) {
-    hipEvent_t e0, e1;
     FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
     FE_HIP(hipEventRecord(e0, c.stream));
-    launch();
+  }
+  launch_gemm(p, c.stream);
+  if (c.profile) {
     FE_HIP(hipEventRecord(e1, c.stream));
     FE_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     FE_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     char nm[128];
-    snprintf(nm, sizeof nm, "bgemm x%d M=%d K=%d N=%d", p.batch > 1 ? p.batch : 1, p.M, p.K, p.Cout);
+    snprintf(nm, sizeof nm, "%sbgemm x%d M=%d K=%d N=%d", sizeof(T) == 2 ? "bf16 " : "", p.batch > 1 ? p.batch : 1, p.M, p.K, p.Cout);
     c.timings.push_back({nm, flops, 0.0, ms});
-  } else {
-    launch_conv(p, c.stream);
   }
   c.flops_accum += flops;
 }
 
-void mha_forward(Ctx& c, const MHAW& m, const float* q_in, int ldq, const float* kv_in, int ldkv, int B, int Lq, int Lk,
-                 const float* res, int ldr, float* y, int ldy, bool causal) {
+static const float* mha_wv(const MHAW& m, const float*) { return m.wv; }
+static const bf16* mha_wv(const MHAW& m, const bf16*) {
+  FE_CHECK(m.wv_h, "mha(bf16): model was not committed under bf16 precision");
+  return m.wv_h;
+}
+
+template <class T>
+void mha_forward(Ctx& c, const MHAW& m, const T* q_in, int ldq, const T* kv_in, int ldkv, int B, int Lq, int Lk,
+                 const T* res, int ldr, T* y, int ldy, bool causal) {
+  constexpr bool half = sizeof(T) == 2;
   const int d = m.d, H = m.heads, hd = d / H;
   const int Lp = (Lk + 31) / 32 * 32;  // padded key count: row stride of the score matrix and of V^T
   const size_t mark = c.arena.mark();
-  float* Q = (float*)c.arena.alloc((size_t)B * Lq * d * sizeof(float));
-  float* K = (float*)c.arena.alloc((size_t)B * Lk * d * sizeof(float));
-  float* Vt = (float*)c.arena.alloc((size_t)B * d * Lp * sizeof(float));
+  T* Q = c.arena.array<T>((size_t)B * Lq * d);
+  T* K = c.arena.array<T>((size_t)B * Lk * d);
+  T* Vt = c.arena.array<T>((size_t)B * d * Lp);
   static const bool no_flash = getenv("FE_NO_FLASH") != nullptr;
-  const bool flash = (hd == 64) && !no_flash;
+  const bool flash = (hd == 64) && (!no_flash || half);
   FE_CHECK(flash || !causal, "causal attention needs the fused kernel (head_dim 64)");
-  float* S = flash ? nullptr : (float*)c.arena.alloc((size_t)B * H * Lq * Lp * sizeof(float));
-  float* O = (float*)c.arena.alloc((size_t)B * Lq * d * sizeof(float));
+  FE_CHECK(flash || !half, "attention(bf16) needs head_dim 64");
+  T* S = flash ? nullptr : c.arena.array<T>((size_t)B * H * Lq * Lp);
+  T* O = c.arena.array<T>((size_t)B * Lq * d);
   linear_forward(c, m.q, q_in, ldq, B * Lq, Q, d, ACT_NONE);
   linear_forward(c, m.k, kv_in, ldkv, B * Lk, K, d, ACT_NONE);
-  if (Lp != Lk) FE_HIP(hipMemsetAsync(Vt, 0, (size_t)B * d * Lp * sizeof(float), c.stream));
+  if (Lp != Lk) FE_HIP(hipMemsetAsync(Vt, 0, (size_t)B * d * Lp * sizeof(T), c.stream));
   {  // V^T[b] [d][Lk] = Wv [d][d] . X_b^T : the token matrix plays the weight operand
-    ConvParams p{};
-    p.x = m.wv; p.ldx = d; p.w = kv_in; p.ldw = ldkv; p.y = Vt; p.ldy = Lp;
+    ConvParamsT<T> p{};
+    p.x = mha_wv(m, q_in); p.ldx = d; p.w = kv_in; p.ldw = ldkv; p.y = Vt; p.ldy = Lp;
     p.M = d; p.K = d; p.Cout = Lk;
     p.batch = B; p.nb1 = 1; p.ws2 = (long long)Lk * ldkv; p.ys2 = (long long)d * Lp;
+    p.pad_store = half ? 1 : 0;      // bf16 stores move 8 columns: the ragged last group lands in the zero padding of V^T
     raw_gemm(c, p, 2.0 * B * d * (double)d * Lk);
   }
   if (flash) {
-    // fused QK^T -> online softmax -> PV (kernels_attn.hip); scores never touch HBM
+    // fused QK^T -> online softmax -> PV (kernels_attn.hip / kernels_attn_bf16.hip); scores never touch HBM
     launch_attention(Q, d, K, d, Vt, Lp, m.bv, O, d, B, H, Lq, Lk, d, causal ? 1 : 0, c.stream);
     c.flops_accum += 4.0 * B * H * (double)Lq * Lk * hd;
-  } else {
-  {  // S[b,h] [Lq][Lk] = Q_bh K_bh^T
+  } else if constexpr (!half) {
+    {  // S[b,h] [Lq][Lk] = Q_bh K_bh^T
       ConvParams p{};
       p.x = Q; p.ldx = d; p.w = K; p.ldw = d; p.y = S; p.ldy = Lp;
       p.M = Lq; p.K = hd; p.Cout = Lk;
@@ -586,5 +724,7 @@ void mha_forward(Ctx& c, const MHAW& m, const float* q_in, int ldq, const float*
   linear_forward(c, m.out, O, d, B * Lq, y, ldy, ACT_NONE, res, ldr);
   c.arena.rewind(mark);
 }
+template void mha_forward<float>(Ctx&, const MHAW&, const float*, int, const float*, int, int, int, int, const float*, int, float*, int, bool);
+template void mha_forward<bf16>(Ctx&, const MHAW&, const bf16*, int, const bf16*, int, int, int, int, const bf16*, int, bf16*, int, bool);
 
 }  // namespace fe

@@ -74,6 +74,23 @@ struct TensorT {
 using Tensor = TensorT<float>;
 using TensorH = TensorT<bf16>;
 
+// element access shared by the fp32 and bf16 instantiations: arithmetic is always fp32, only loads / stores differ
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16* p) { return (float)*p; }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16* p, float v) { *p = (bf16)v; }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16* p, float4 v) {
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  bf4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+  *reinterpret_cast<bf4*>(p) = o;
+}
+
 // Bump allocator over one hipMalloc'ed slab; reset per forward. 256-B aligned.
 class Arena {
  public:
@@ -189,8 +206,9 @@ void launch_wino_output(const float* Mb, const Tensor& y, int th, int tw, const 
 void launch_wino4_input(const Tensor& x, int th, int tw, float* V, hipStream_t s);     // F(4x4,3x3): [36][tiles][C] planes
 void launch_wino4_output(const float* Mb, const Tensor& y, int th, int tw, const float* scale, const float* shift, int act, const float* slope,
                          const Tensor* res, int res_after_act, hipStream_t s);
+template <class TO>   // TO = float | bf16: the stem always reads fp32 NHWC4 pixels; it can hand bf16 activations to the bf16 path
 bool launch_stem(const float* x, int ldx, int N, int H, int W, const float* wstem, const float* scale, const float* shift, const float* slope,
-                 int Cout, int k, int stride, int act, float* y, int ldy, int Ho, int Wo, hipStream_t s);   // kernels_stem.hip; false = shape not handled
+                 int Cout, int k, int stride, int act, TO* y, int ldy, int Ho, int Wo, hipStream_t s);   // kernels_stem.hip; false = shape not handled
 void launch_conv_narrow(const ConvParams& p, hipStream_t s);            // Cout <= 4, no MFMA (kernels_misc.hip)
 void launch_conv_dma(const ConvParams& p, int tile, hipStream_t s);  // LDS-DMA fast path (kernels_conv_dma.hip)
 void launch_conv_bf16(const ConvParamsH& p, hipStream_t s);          // bf16 MFMA implicit GEMM (kernels_conv_bf16.hip)
@@ -225,6 +243,9 @@ void launch_tap_gather(const T* z, int ldz, int n, int h, int w, int kh, int kw,
                        hipStream_t s);
 // fused attention, head_dim 64 (kernels_attn.hip): o = softmax(q k^T) v + bv per (batch, head)
 void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* vt, int lp, const float* bv, float* o,
+                      int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s);
+// bf16 twin (kernels_attn_bf16.hip): bf16 Q / K / V^T / O, fp32 softmax and accumulation
+void launch_attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* vt, int lp, const float* bv, bf16* o,
                       int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s);
 // M <= 32 rows: one wave per output column (kernels_misc.hip); TI / TW / TO = activation / weight / output element types
 template <class TI, class TW, class TO>

@@ -5,22 +5,6 @@
 
 namespace fe {
 
-// element access shared by the fp32 and bf16 instantiations: arithmetic is always fp32, only loads / stores differ
-__device__ __forceinline__ float ldf(const float* p) { return *p; }
-__device__ __forceinline__ float ldf(const bf16* p) { return (float)*p; }
-__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
-__device__ __forceinline__ void stf(bf16* p, float v) { *p = (bf16)v; }
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float4 ld4(const bf16* p) {
-  const uint2 u = *reinterpret_cast<const uint2*>(p);
-  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
-}
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ void st4(bf16* p, float4 v) {
-  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-  bf4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
-  *reinterpret_cast<bf4*>(p) = o;
-}
 template <class T> static inline bool vec4_ok(const T* a, const T* b) { return (((uintptr_t)a | (uintptr_t)b) & (4 * sizeof(T) - 1)) == 0; }
 
 static inline int grid_for(size_t work, int block = 256) {

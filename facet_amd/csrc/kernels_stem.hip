@@ -16,19 +16,20 @@ namespace fe {
 typedef float stem_f32x16 __attribute__((ext_vector_type(16)));
 typedef float stem_v4f __attribute__((ext_vector_type(4)));
 
-struct StemParams {
+template <class TO>              // TO: output element type (float, or bf16 when the stem feeds the bf16 path)
+struct StemParamsT {
   const float* x; int ldx;      // NHWC fp32, >= 4 floats per pixel (channel 3 is ignored)
   const float* w;               // [TAPS2][Cout][4]: tap-major so the 32 lanes of a fragment read consecutive 16-B words; channel 3 and the padding tap are zero
   const float* scale; const float* shift;
-  float* y; int ldy;
+  TO* y; int ldy;
   const float* slope;           // PReLU slopes (act == 2)
   int N, H, W, Ho, Wo, Cout, act;   // act: 0 none, 1 relu, 2 prelu
 };
 
 constexpr int STEM_TH = 8, STEM_TW = 32;
 
-template <int TN, int STEM_K, int STEM_S>   // TN = Cout / 32; square kernel STEM_K, stride STEM_S, padding STEM_K / 2
-__global__ __launch_bounds__(256, 2) void stem_kernel(StemParams p) {
+template <int TN, int STEM_K, int STEM_S, class TO>   // TN = Cout / 32; square kernel STEM_K, stride STEM_S, padding STEM_K / 2
+__global__ __launch_bounds__(256, 2) void stem_kernel(StemParamsT<TO> p) {
   constexpr int STEM_P = STEM_K / 2;
   constexpr int STEM_PH = (STEM_TH - 1) * STEM_S + STEM_K;   // 7x7/2: 21 patch rows
   constexpr int STEM_PW = (STEM_TW - 1) * STEM_S + STEM_K;   // 7x7/2: 69 patch columns
@@ -115,45 +116,50 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemParams p) {
     v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
     if (p.act == 1) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
     else if (p.act == 2) { v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y; v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w; }
-    if (oy < p.Ho && ox < p.Wo) *reinterpret_cast<float4*>(p.y + (((size_t)img * p.Ho + oy) * p.Wo + ox) * p.ldy + c4) = v;
+    if (oy < p.Ho && ox < p.Wo) st4(p.y + (((size_t)img * p.Ho + oy) * p.Wo + ox) * p.ldy + c4, v);
   }
 }
 
-template <int TN, int K, int S>
-static void launch_stem_t(const StemParams& p, hipStream_t s) {
+template <int TN, int K, int S, class TO>
+static void launch_stem_t(const StemParamsT<TO>& p, hipStream_t s) {
   constexpr int PH = (STEM_TH - 1) * S + K, PW = (STEM_TW - 1) * S + K, T2 = (K * K + 1) & ~1;
   constexpr size_t main_lds = ((size_t)PH * PW * 4 + (size_t)TN * 32 * T2 * 4) * sizeof(float);
   constexpr size_t epi_lds = (size_t)4 * 64 * (TN * 32 + 4) * sizeof(float);     // four wave-private transpose regions
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   static std::atomic<uint64_t> lds_set{0};
-  ensure_dynamic_lds((const void*)stem_kernel<TN, K, S>, lds, lds_set);
+  ensure_dynamic_lds((const void*)stem_kernel<TN, K, S, TO>, lds, lds_set);
   const dim3 grid((p.Wo + STEM_TW - 1) / STEM_TW, (p.Ho + STEM_TH - 1) / STEM_TH, p.N);
-  hipLaunchKernelGGL((stem_kernel<TN, K, S>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((stem_kernel<TN, K, S, TO>), grid, dim3(256), lds, s, p);
   FE_HIP(hipGetLastError());
 }
 
 // wstem: [taps padded to even][Cout][4]; Cout 32 or 64; (k, stride) one of (7,2) (3,1) (3,2), padding k/2; act 0 none / 1 relu /
 // 2 prelu(slope). Returns false when the shape is not one of these (the caller falls back to the generic kernel).
+template <class TO>
 bool launch_stem(const float* x, int ldx, int N, int H, int W, const float* wstem, const float* scale, const float* shift, const float* slope,
-                 int Cout, int k, int stride, int act, float* y, int ldy, int Ho, int Wo, hipStream_t s) {
+                 int Cout, int k, int stride, int act, TO* y, int ldy, int Ho, int Wo, hipStream_t s) {
   const int pad = k / 2;
   if (!(Cout == 32 || Cout == 64) || ldx < 4 || ldx % 4 || ldy % 4 || Ho != (H + 2 * pad - k) / stride + 1 || Wo != (W + 2 * pad - k) / stride + 1 ||
-      (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wstem) & 15) || (act == 2 && !slope) || act < 0 || act > 2)
+      (((uintptr_t)x | (uintptr_t)wstem) & 15) || ((uintptr_t)y & (4 * sizeof(TO) - 1)) || (act == 2 && !slope) || act < 0 || act > 2)
     return false;
-  StemParams p{x, ldx, wstem, scale, shift, y, ldy, slope, N, H, W, Ho, Wo, Cout, act};
+  StemParamsT<TO> p{x, ldx, wstem, scale, shift, y, ldy, slope, N, H, W, Ho, Wo, Cout, act};
   const int key = k * 10 + stride;
   if (Cout == 64) {
-    if (key == 72) launch_stem_t<2, 7, 2>(p, s);
-    else if (key == 31) launch_stem_t<2, 3, 1>(p, s);
-    else if (key == 32) launch_stem_t<2, 3, 2>(p, s);
+    if (key == 72) launch_stem_t<2, 7, 2, TO>(p, s);
+    else if (key == 31) launch_stem_t<2, 3, 1, TO>(p, s);
+    else if (key == 32) launch_stem_t<2, 3, 2, TO>(p, s);
     else return false;
   } else {
-    if (key == 72) launch_stem_t<1, 7, 2>(p, s);
-    else if (key == 31) launch_stem_t<1, 3, 1>(p, s);
-    else if (key == 32) launch_stem_t<1, 3, 2>(p, s);
+    if (key == 72) launch_stem_t<1, 7, 2, TO>(p, s);
+    else if (key == 31) launch_stem_t<1, 3, 1, TO>(p, s);
+    else if (key == 32) launch_stem_t<1, 3, 2, TO>(p, s);
     else return false;
   }
   return true;
 }
+template bool launch_stem<float>(const float*, int, int, int, int, const float*, const float*, const float*, const float*, int, int, int, int, float*, int, int, int,
+                                 hipStream_t);
+template bool launch_stem<bf16>(const float*, int, int, int, int, const float*, const float*, const float*, const float*, int, int, int, int, bf16*, int, int, int,
+                                hipStream_t);
 
 }  // namespace fe

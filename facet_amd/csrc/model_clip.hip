@@ -135,15 +135,17 @@ void build_aesthetic(AestheticModel& m, const WeightStore& ws) {
   m.l2 = build_linear(m.dw, ws, "2", true);
 }
 
-// tok[b][0] = cls + pos[0]; tok[b][1+p] += pos[1+p]
-__global__ void clip_embed_kernel(float* __restrict__ tok, const float* __restrict__ cls, const float* __restrict__ pos,
-                                  int B, int T, int d) {
-  const size_t total = (size_t)B * T * d;
+// tok[b][0] = cls + pos[0]; tok[b][1+p] = patch[b][1+p] + pos[1+p]. patch = the fp32 output of the patch-embed GEMM (rows 1..T-1
+// of every image); tok has the activation type of the tower (in place when both are fp32).
+template <class T>
+__global__ void clip_embed_kernel(const float* patch, T* tok, const float* __restrict__ cls, const float* __restrict__ pos,
+                                  int B, int Tk, int d) {
+  const size_t total = (size_t)B * Tk * d;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = i % d;
-    const int tkn = (i / d) % T;
+    const int tkn = (i / d) % Tk;
     const float pe = pos[(size_t)tkn * d + c];
-    tok[i] = tkn == 0 ? cls[c] + pe : tok[i] + pe;
+    stf(tok + i, tkn == 0 ? cls[c] + pe : patch[i] + pe);
   }
 }
 
@@ -160,45 +162,51 @@ __global__ void l2_normalize_kernel(const float* __restrict__ x, float* __restri
   for (int i = lane; i < d; i += 64) y[(size_t)row * d + i] = x[(size_t)row * d + i] * inv;
 }
 
-// x: [B,224,224,4] (CLIP-normalised, 4th channel zero) -> feat: device [B][out_dim] (un-normalised features)
+// x: [B,224,224,4] fp32 (CLIP-normalised, 4th channel zero) -> feat: device fp32 [B][out_dim] (un-normalised features).
+// T = activation type of the tower (float | bf16): the 3-channel patch embedding always runs on the fp32 kernel, the last
+// projection always emits fp32.
+template <class T>
 void clip_forward(Ctx& c, const ClipModel& m, const Tensor& x, float* feat) {
   const size_t mark = c.arena.mark();
-  const int B = x.n, d = m.width, T = m.tokens, P = m.patch_size;
+  const int B = x.n, d = m.width, Tk = m.tokens, P = m.patch_size;
   const int gh = x.h / P, gw = x.w / P;
-  FE_CHECK(gh * gw + 1 == T, "clip: %dx%d input gives %d patches, positional_embedding has %d tokens", x.h, x.w, gh * gw, T);
-  float* tok = (float*)c.arena.alloc((size_t)B * T * d * sizeof(float));
-  {  // patch embed, one batch entry per image so rows land at tok[b][1 + patch]
+  FE_CHECK(gh * gw + 1 == Tk, "clip: %dx%d input gives %d patches, positional_embedding has %d tokens", x.h, x.w, gh * gw, Tk);
+  T* tok = c.arena.array<T>((size_t)B * Tk * d);
+  float* patch = sizeof(T) == 4 ? reinterpret_cast<float*>(tok) : c.arena.array<float>((size_t)B * Tk * d);
+  {  // patch embed, one batch entry per image so rows land at patch[b][1 + p]
     ConvParams p{};
-    p.x = x.p; p.ldx = x.ld; p.w = m.patch.w; p.y = tok + d; p.ldy = d;
+    p.x = x.p; p.ldx = x.ld; p.w = m.patch.w; p.y = patch + d; p.ldy = d;
     p.N = 1; p.H = x.h; p.W = x.w; p.Cin = m.patch.CinPad; p.Ho = gh; p.Wo = gw; p.Cout = d;
     p.KH = p.KW = P; p.sh = p.sw = P; p.dh = p.dw = 1;
     p.K = m.patch.K; p.Kp = m.patch.Kp; p.M = gh * gw;
-    p.batch = B; p.nb1 = 1; p.xs2 = (long long)x.h * x.w * x.ld; p.ys2 = (long long)T * d;
+    p.batch = B; p.nb1 = 1; p.xs2 = (long long)x.h * x.w * x.ld; p.ys2 = (long long)Tk * d;
     launch_conv(p, c.stream);
     c.flops_accum += 2.0 * B * p.M * (double)(P * P * m.patch.Cin) * d;
   }
-  hipLaunchKernelGGL(clip_embed_kernel, dim3(2048), dim3(256), 0, c.stream, tok, m.cls, m.pos, B, T, d);
+  hipLaunchKernelGGL(clip_embed_kernel<T>, dim3(2048), dim3(256), 0, c.stream, patch, tok, m.cls, m.pos, B, Tk, d);
   FE_HIP(hipGetLastError());
-  const int rows = B * T;
-  float* xa = (float*)c.arena.alloc((size_t)rows * d * sizeof(float));
-  float* nb = (float*)c.arena.alloc((size_t)rows * d * sizeof(float));
-  float* hb = (float*)c.arena.alloc((size_t)rows * 4 * d * sizeof(float));
+  const int rows = B * Tk;
+  T* xa = c.arena.array<T>((size_t)rows * d);
+  T* nb = c.arena.array<T>((size_t)rows * d);
+  T* hb = c.arena.array<T>((size_t)rows * 4 * d);
   launch_layernorm(tok, d, xa, d, m.ln_pre.g, m.ln_pre.b, rows, d, m.ln_pre.eps, c.stream);
-  float* cur = xa;
-  float* other = tok;
+  T* cur = xa;
+  T* other = tok;
   for (const ClipBlockW& w : m.blocks) {
     launch_layernorm(cur, d, nb, d, w.ln1.g, w.ln1.b, rows, d, w.ln1.eps, c.stream);
-    mha_forward(c, w.attn, nb, d, nb, d, B, T, T, cur, d, other, d);          // other = cur + attn(ln1(cur))
+    mha_forward<T>(c, w.attn, nb, d, nb, d, B, Tk, Tk, cur, d, other, d);          // other = cur + attn(ln1(cur))
     launch_layernorm(other, d, nb, d, w.ln2.g, w.ln2.b, rows, d, w.ln2.eps, c.stream);
     linear_forward(c, w.fc, nb, d, rows, hb, w.fc.Cout, ACT_GELU);
     linear_forward(c, w.proj, hb, w.fc.Cout, rows, cur, d, ACT_NONE, other, d);  // cur = other + mlp(ln2(other))
   }
-  // ln_post on the class token of every image (row stride T*d), then the projection
-  float* pooled = (float*)c.arena.alloc((size_t)B * d * sizeof(float));
-  launch_layernorm(cur, T * d, pooled, d, m.ln_post.g, m.ln_post.b, B, d, m.ln_post.eps, c.stream);
-  linear_forward(c, m.proj, pooled, d, B, feat, m.out_dim, ACT_NONE);
+  // ln_post on the class token of every image (row stride Tk*d), then the projection (fp32 out)
+  T* pooled = c.arena.array<T>((size_t)B * d);
+  launch_layernorm(cur, Tk * d, pooled, d, m.ln_post.g, m.ln_post.b, B, d, m.ln_post.eps, c.stream);
+  linear_forward_f32(c, m.proj, pooled, d, B, feat, m.out_dim, ACT_NONE);
   c.arena.rewind(mark);
 }
+template void clip_forward<float>(Ctx&, const ClipModel&, const Tensor&, float*);
+template void clip_forward<bf16>(Ctx&, const ClipModel&, const Tensor&, float*);
 
 // raw[b] = Linear(256,1)(relu(Linear(768,256)(feat[b])))   (reference scorer.py:579-583; (x+1)*5 clamp stays on host)
 void aesthetic_forward(Ctx& c, const AestheticModel& m, const float* feat, int B, float* raw) {

@@ -137,19 +137,21 @@ static float* topiq_pos(TopiqModel& m, int th, int tw) {
   return dev;
 }
 
-static void ln(Ctx& c, const LayerNormW& l, const float* x, float* y, int rows) {
+template <class T>
+static void ln(Ctx& c, const LayerNormW& l, const T* x, T* y, int rows) {
   launch_layernorm(x, l.d, y, l.d, l.g, l.b, rows, l.d, l.eps, c.stream);
 }
 
 // x, y: [B*L][d]; y may alias x. Pre-norm encoder layer (q = k = v = norm1(x)).
-static void enc_forward(Ctx& c, const EncLayerW& e, float* x, float* y, int B, int L) {
+template <class T>
+static void enc_forward(Ctx& c, const EncLayerW& e, T* x, T* y, int B, int L) {
   const int d = e.n1.d, rows = B * L, ff = e.lin1.Cout;
   const size_t mark = c.arena.mark();
-  float* n = (float*)c.arena.alloc((size_t)rows * d * sizeof(float));
-  float* a = (float*)c.arena.alloc((size_t)rows * d * sizeof(float));
-  float* hbuf = (float*)c.arena.alloc((size_t)rows * ff * sizeof(float));
+  T* n = c.arena.array<T>((size_t)rows * d);
+  T* a = c.arena.array<T>((size_t)rows * d);
+  T* hbuf = c.arena.array<T>((size_t)rows * ff);
   ln(c, e.n1, x, n, rows);
-  mha_forward(c, e.attn, n, d, n, d, B, L, L, x, d, a, d);
+  mha_forward<T>(c, e.attn, n, d, n, d, B, L, L, x, d, a, d);
   ln(c, e.n2, a, n, rows);
   linear_forward(c, e.lin1, n, d, rows, hbuf, ff, ACT_GELU);
   linear_forward(c, e.lin2, hbuf, ff, rows, y, d, ACT_NONE, a, d);
@@ -157,69 +159,76 @@ static void enc_forward(Ctx& c, const EncLayerW& e, float* x, float* y, int B, i
 }
 
 // tgt: [B*Lq][d] (updated in place), memory: [B*Lk][d]
-static void dec_forward(Ctx& c, const DecLayerW& w, float* tgt, const float* memory, int B, int Lq, int Lk) {
+template <class T>
+static void dec_forward(Ctx& c, const DecLayerW& w, T* tgt, const T* memory, int B, int Lq, int Lk) {
   const int d = w.n1.d, ff = w.lin1.Cout;
   const size_t mark = c.arena.mark();
-  float* mem = (float*)c.arena.alloc((size_t)B * Lk * d * sizeof(float));
-  float* t2 = (float*)c.arena.alloc((size_t)B * Lq * d * sizeof(float));
-  float* a = (float*)c.arena.alloc((size_t)B * Lq * d * sizeof(float));
-  float* hbuf = (float*)c.arena.alloc((size_t)B * Lq * ff * sizeof(float));
+  T* mem = c.arena.array<T>((size_t)B * Lk * d);
+  T* t2 = c.arena.array<T>((size_t)B * Lq * d);
+  T* a = c.arena.array<T>((size_t)B * Lq * d);
+  T* hbuf = c.arena.array<T>((size_t)B * Lq * ff);
   ln(c, w.n2, memory, mem, B * Lk);
-  ln(c, w.n1, tgt, t2, B * Lq);
-  mha_forward(c, w.cross, t2, d, mem, d, B, Lq, Lk, tgt, d, a, d);
-  ln(c, w.n3, a, t2, B * Lq);
+  ln(c, w.n1, (const T*)tgt, t2, B * Lq);
+  mha_forward<T>(c, w.cross, t2, d, mem, d, B, Lq, Lk, tgt, d, a, d);
+  ln(c, w.n3, (const T*)a, t2, B * Lq);
   linear_forward(c, w.lin1, t2, d, B * Lq, hbuf, ff, ACT_GELU);
   linear_forward(c, w.lin2, hbuf, ff, B * Lq, tgt, d, ACT_NONE, a, d);
   c.arena.rewind(mark);
 }
 
-void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<Tensor>& feats, float* scores_dev) {
+// T = activation type (float | bf16). With bf16 the head stays bf16 up to the token mean; the MOS MLP (LayerNorm - Linear - GELU -
+// LayerNorm - Linear - GELU - Linear on one 256-vector per image) always runs in fp32 on the fp32 copies of its weights.
+template <class T>
+void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<TensorT<T>>& feats, float* scores_dev) {
   FE_CHECK(m.has_head && feats.size() == 5, "topiq head: not built / bad pyramid");
   const int B = feats[0].n;
   const int th = feats[4].h, tw = feats[4].w, L = th * tw, d = 256;
   const float* pos = topiq_pos(m, th, tw);
-  float* tok[5];
-  for (int i = 0; i < 5; ++i) tok[i] = (float*)c.arena.alloc((size_t)B * L * d * sizeof(float));
+  T* tok[5];
+  for (int i = 0; i < 5; ++i) tok[i] = c.arena.array<T>((size_t)B * L * d);
   for (int i = 4; i >= 0; --i) {
     const size_t mark = c.arena.mark();
-    const Tensor& f = feats[i];
+    const TensorT<T>& f = feats[i];
     const GatedConvW& g = m.gate[i];
-    ConvOpts o0; o0.act = m.wblk_act;
-    Tensor wa = conv_new(c, g.w0, f, o0);    // = act(weight_blk[0](x2)) with x2 folded in (see build_topiq_head)
-    ConvOpts o2; o2.act = m.wblk_act; o2.ph = o2.pw = 1;
-    Tensor wb = conv_new(c, g.w2, wa, o2);
-    ConvOpts o4; o4.act = ACT_SIGMOID; o4.ph = o4.pw = 1;
-    Tensor wc = conv_new(c, g.w4, wb, o4);
-    ConvOpts og; og.act = m.gate_act; og.gate = &wc;   // act(x1) * weight
-    Tensor gated = conv_new(c, g.split_x1, f, og);
+    ConvOptsT<T> o0; o0.act = m.wblk_act;
+    TensorT<T> wa = conv_new(c, g.w0, f, o0);    // = act(weight_blk[0](x2)) with x2 folded in (see build_topiq_head)
+    ConvOptsT<T> o2; o2.act = m.wblk_act; o2.ph = o2.pw = 1;
+    TensorT<T> wb = conv_new(c, g.w2, wa, o2);
+    ConvOptsT<T> o4; o4.act = ACT_SIGMOID; o4.ph = o4.pw = 1;
+    TensorT<T> wc = conv_new(c, g.w4, wb, o4);
+    ConvOptsT<T> og; og.act = m.gate_act; og.gate = &wc;   // act(x1) * weight
+    TensorT<T> gated = conv_new(c, g.split_x1, f, og);
     if (gated.h > th && gated.w > tw) {
-      Tensor pooled = c.arena.tensor(B, th, tw, gated.c);
+      TensorT<T> pooled = c.arena.tensor_t<T>(B, th, tw, gated.c);
       launch_adaptive_avgpool(gated, pooled, c.stream);
       gated = pooled;
     }
     FE_CHECK(gated.h == th && gated.w == tw, "topiq head: level %d is %dx%d, expected %dx%d", i, gated.h, gated.w, th, tw);
-    Tensor t = mat_view(tok[i], B * L, d, d);
+    TensorT<T> t = mat_view(tok[i], B * L, d, d);
     t.n = B; t.h = th; t.w = tw;
-    ConvOpts od; od.act = ACT_GELU;
+    ConvOptsT<T> od; od.act = ACT_GELU;
     conv_forward(c, m.dim_reduce[i], gated, t, od);
     launch_add_rows_bcast(tok[i], d, pos, B * L, L, d, c.stream);
     enc_forward(c, m.sa[i], tok[i], tok[i], B, L);
     c.arena.rewind(mark);
   }
-  float* query = tok[4];
-  for (int i = 0; i < 4; ++i) dec_forward(c, m.cross[i], query, tok[3 - i], B, L, L);
+  T* query = tok[4];
+  for (int i = 0; i < 4; ++i) dec_forward(c, m.cross[i], query, (const T*)tok[3 - i], B, L, L);
   enc_forward(c, m.pool, query, query, B, L);
-  // mean over tokens, then the MOS MLP
-  Tensor fin; fin.p = query; fin.n = B; fin.h = 1; fin.w = L; fin.c = d; fin.ld = d;
-  Tensor mean = c.arena.tensor(B, 1, 1, d);
+  // mean over tokens, then the MOS MLP (fp32)
+  TensorT<T> fin; fin.p = query; fin.n = B; fin.h = 1; fin.w = L; fin.c = d; fin.ld = d;
+  TensorT<T> mean = c.arena.tensor_t<T>(B, 1, 1, d);
   launch_adaptive_avgpool(fin, mean, c.stream);
-  float* a = (float*)c.arena.alloc((size_t)B * d * sizeof(float));
-  float* b = (float*)c.arena.alloc((size_t)B * d * sizeof(float));
-  ln(c, m.s_ln0, mean.p, a, B);
-  linear_forward(c, m.s_l1, a, d, B, b, d, ACT_GELU);
-  ln(c, m.s_ln3, b, a, B);
-  linear_forward(c, m.s_l4, a, d, B, b, d, ACT_GELU);
-  linear_forward(c, m.s_l6, b, d, B, scores_dev, 1, ACT_NONE);
+  float* a = c.arena.array<float>((size_t)B * d);
+  float* b = c.arena.array<float>((size_t)B * d);
+  const float* mean_f = to_f32(c, mean.p, (size_t)B * d);
+  launch_layernorm(mean_f, d, a, d, m.s_ln0.g, m.s_ln0.b, B, d, m.s_ln0.eps, c.stream);
+  linear_forward(c, m.s_l1, (const float*)a, d, B, b, d, ACT_GELU);
+  launch_layernorm((const float*)b, d, a, d, m.s_ln3.g, m.s_ln3.b, B, d, m.s_ln3.eps, c.stream);
+  linear_forward(c, m.s_l4, (const float*)a, d, B, b, d, ACT_GELU);
+  linear_forward(c, m.s_l6, (const float*)b, d, B, scores_dev, 1, ACT_NONE);
 }
+template void topiq_head_forward<float>(Ctx&, TopiqModel&, const std::vector<Tensor>&, float*);
+template void topiq_head_forward<bf16>(Ctx&, TopiqModel&, const std::vector<TensorH>&, float*);
 
 }  // namespace fe

@@ -58,6 +58,15 @@ int fe_sync(fe_ctx* ctx);
 /* images processed per engine pass inside the batched entry points (activation footprint knob) */
 int fe_set_microbatch(fe_ctx* ctx, int n);
 
+/* Precision of the models committed AFTER this call (each model keeps the one it was committed under; FE_MODEL_AESTHETIC, the CLIP
+ * text tower and the ONNX face graphs always run in fp32). FE_PRECISION_BF16 = BASELINE.json configs[3]: bf16 activations and weights
+ * in HBM on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16) with fp32 accumulation, fp32 LayerNorm / softmax statistics, fp32 score
+ * heads and fp32 outputs; the 3-channel first layers stay on the fp32 kernels. The reference does the same on a GPU for CLIP
+ * (`model.half()`, processing/scorer.py:513-516). Default FE_PRECISION_F32 (the reference's CPU path). */
+enum fe_precision { FE_PRECISION_F32 = 0, FE_PRECISION_BF16 = 1 };
+int fe_set_precision(fe_ctx* ctx, int precision);
+int fe_model_precision(fe_ctx* ctx, int model); /* fe_precision of a loaded model, -1 when it is not loaded */
+
 /* ---- device buffers (so callers can keep batches resident in HBM without torch) ------------- */
 int fe_dev_alloc(fe_ctx* ctx, size_t bytes, void** d_out);
 int fe_dev_free(fe_ctx* ctx, void* d_ptr);
