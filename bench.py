@@ -38,12 +38,22 @@ sys.path.insert(0, ROOT)
 METRIC = "images/sec whole-node (TOPIQ+SAMP+CLIP+InsightFace ensemble), 1024² batch"
 FACES_PER_IMAGE = 2
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: bf16 MFMA dense peak (~2.5 PF; the 5 PF headline includes 2:1 sparsity)
 WORKLOADS = ["full", "topiq", "topiq_clip", "ensemble", "faces"]
 # which models a workload runs: ensemble mask (1 topiq | 2 clip | 4 samp) and whether the face stage runs
 WL = {"topiq": (1, False), "topiq_clip": (3, False), "ensemble": (7, False), "faces": (5, True), "full": (7, True)}
 
 
-def workload_text(wl, B, HW):
+def workload_text(wl, B, HW, dtype="f32"):
+    t = _workload_text(wl, B, HW)
+    if dtype == "bf16":
+        t = t.replace(" fp32", " bf16 (bf16 activations / weights, fp32 accumulate, fp32 first layers + LayerNorm / softmax statistics + score heads)")
+        if wl == "ensemble":
+            t = t.replace("(no InsightFace; the fp32 form of BASELINE configs[3])", "(BASELINE configs[3]: the 16gb profile in bf16)")
+    return t
+
+
+def _workload_text(wl, B, HW):
     face = (f"InsightFace-style SCRFD detect @640 + 2d106 landmarks + ArcFace-R50 ({FACES_PER_IMAGE} best faces/image, seeded "
             "stand-in ONNX graphs of the buffalo_l architectures)")
     return {
@@ -179,6 +189,9 @@ def main():
                          "ViT-L/14 + aesthetic MLP; faces = configs[2]: TOPIQ + SAMP-Net + SCRFD/landmarks/ArcFace")
     ap.add_argument("--cpu-sample", type=int, default=2, help="images for the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-sub", action="store_true", help="skip the configs[1] / TOPIQ+CLIP sub-measurements")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="precision of TOPIQ / SAMP-Net / U2-Net-P / CLIP for the primary workload (faces graphs always fp32); the headline "
+                         "stays f32 = the reference CPU path's arithmetic, bf16 = BASELINE configs[3]")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / gather path only, no engine (CPU test hook, gloo)")
     args = ap.parse_args()
 
@@ -238,24 +251,31 @@ def main():
         need_mask |= WL[w][0]
     need_faces = any(WL[w][1] for w in need)
 
-    eng = Engine(dev_index, arena_bytes=(4 + 2 * args.microbatch * max(1, (HW * HW) // (1024 * 1024))) << 30)
-    eng.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", seed=3))
-    if need_mask & 2:
-        eng.load_weights(FE_MODEL_CLIP, synthetic_state_dict("clip", seed=3))
-        eng.load_weights(FE_MODEL_AESTHETIC, synthetic_state_dict("aesthetic", seed=3))
-    if need_mask & 4:
-        eng.load_weights(FE_MODEL_U2NETP, synthetic_state_dict("u2netp", seed=3))
-        eng.load_weights(FE_MODEL_SAMP, synthetic_state_dict("samp_net", seed=3))
-    if need_faces:
-        # BASELINE.json configs[2] / the metric's InsightFace stage. Seeded stand-in graphs of the buffalo_l architectures
-        # (no model files offline); uniform-noise images carry no real faces, so the best FACES_PER_IMAGE detections of the
-        # synthetic detector go through landmarks + ArcFace (fixed faces-per-image mode).
-        from facet_amd import synthetic_onnx as SO
-        from facet_amd._lib import FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC
-        eng.graph_load(FE_GRAPH_FACE_DET, SO.scrfd_like(seed=12, size=640)[0])
-        eng.graph_load(FE_GRAPH_FACE_LMK, SO.landmark_like(seed=13)[0])
-        eng.graph_load(FE_GRAPH_FACE_REC, SO.arcface_iresnet(seed=14)[0])
-    eng.set_microbatch(args.microbatch)
+    def make_engine(precision, mask, faces):
+        e = Engine(dev_index, arena_bytes=(4 + 2 * args.microbatch * max(1, (HW * HW) // (1024 * 1024))) << 30, precision=precision)
+        e.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", seed=3))
+        if mask & 2:
+            e.load_weights(FE_MODEL_CLIP, synthetic_state_dict("clip", seed=3))
+            e.load_weights(FE_MODEL_AESTHETIC, synthetic_state_dict("aesthetic", seed=3))
+        if mask & 4:
+            e.load_weights(FE_MODEL_U2NETP, synthetic_state_dict("u2netp", seed=3))
+            e.load_weights(FE_MODEL_SAMP, synthetic_state_dict("samp_net", seed=3))
+        if faces:
+            # BASELINE.json configs[2] / the metric's InsightFace stage. Seeded stand-in graphs of the buffalo_l architectures
+            # (no model files offline); uniform-noise images carry no real faces, so the best FACES_PER_IMAGE detections of the
+            # synthetic detector go through landmarks + ArcFace (fixed faces-per-image mode).
+            from facet_amd import synthetic_onnx as SO
+            from facet_amd._lib import FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC
+            e.graph_load(FE_GRAPH_FACE_DET, SO.scrfd_like(seed=12, size=640)[0])
+            e.graph_load(FE_GRAPH_FACE_LMK, SO.landmark_like(seed=13)[0])
+            e.graph_load(FE_GRAPH_FACE_REC, SO.arcface_iresnet(seed=14)[0])
+        e.set_microbatch(args.microbatch)
+        return e
+
+    eng = make_engine(args.dtype, need_mask, need_faces)
+    engines = {args.dtype: eng}
+    if not (args.no_sub or world > 1) and args.dtype == "f32":
+        engines["bf16"] = make_engine("bf16", 7, False)     # second context for the configs[3] sub-measurement
 
     # this rank's shard of the global batch (weak scaling: B images per GPU), generated once, resident in HBM
     lo, hi = shard_range(B * world, world, rank)
@@ -275,7 +295,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_step(wl):
+    def make_step(wl, eng):
         mask, faces = WL[wl]
         if wl == "topiq":
             return lambda: gather_scores(eng.topiq_score(images), world, dev_index)
@@ -288,9 +308,9 @@ def main():
             return rec
         return step
 
-    def measure(wl, steps, warmup):
+    def measure(wl, steps, warmup, eng):
         eng.ensemble_select(WL[wl][0])
-        step = make_step(wl)
+        step = make_step(wl, eng)
         for _ in range(warmup):
             step()
         eng.flops_reset()
@@ -308,7 +328,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), ev_ms, eng.flops(), eng.flops_executed()
 
-    def per_launch(wl):
+    def per_launch(wl, eng):
         """Per-launch view of the dominant kernel family (rank 0, outside the timed region): one micro-batch with a HIP event pair
         around every contraction launch (engine profile mode; the per-launch sync makes it slightly pessimistic). The averages are
         what `rocprofv3 --kernel-trace --stats` reports for conv_dma_kernel (profiles/)."""
@@ -330,22 +350,26 @@ def main():
                 "note": "contraction launches only (conv_dma_kernel / conv_igemm_kernel / stem_kernel; face graphs excluded), "
                         "algorithmic FLOPs / summed launch durations of one micro-batch"}
 
-    def roofline(wl, steps, ev_ms, flops, flops_exec):
+    def roofline(wl, steps, ev_ms, flops, flops_exec, eng, dtype):
         achieved = flops_exec / (ev_ms * 1e-3) / 1e12
-        traffic, tfile = traffic_bytes(wl, HW, B)
-        return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        traffic, tfile = traffic_bytes(wl + ("_bf16" if dtype == "bf16" else ""), HW, B)
+        peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+        kern = ("conv_bf16_kernel (bf16 v_mfma_f32_32x32x16_bf16 implicit GEMM) + attn_fwd_bf16_kernel; the 3-channel first layers run on the fp32 "
+                "stem / generic kernels; every contraction launched in the timed region" if dtype == "bf16" else
+                "conv_dma_kernel + conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; every contraction launched in the timed region)")
+        return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": f"bytes per step per GPU (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{tfile})" if tfile else None,
-                "kernel": "conv_dma_kernel + conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM; every contraction launched in the timed region)",
+                "kernel": kern,
                 "effective_tflops": round(flops / (ev_ms * 1e-3) / 1e12, 2),
                 "flops_per_image": round(flops / (B * steps), 1),
                 "executed_flops_per_image": round(flops_exec / (B * steps), 1),
                 "note": "achieved / frac count the FLOPs the matrix cores executed: 3x3 stride-1 pad-1 convs with >= 96 input channels run as "
                         "Winograd F(4x4,3x3) (36 batched GEMMs per launch, 4x fewer multiply-adds); effective_tflops divides the direct "
                         "convolution's (algorithmic) FLOPs by the same time",
-                "event_ms": round(ev_ms, 3), "per_launch": per_launch(wl) if rank == 0 else None}
+                "event_ms": round(ev_ms, 3), "per_launch": per_launch(wl, eng) if rank == 0 else None}
 
-    dt_max, ev_ms, flops, flops_exec = measure(primary, args.steps, args.warmup)
+    dt_max, ev_ms, flops, flops_exec = measure(primary, args.steps, args.warmup, eng)
     out = None
     if rank == 0:
         total_images = B * world * args.steps
@@ -353,22 +377,26 @@ def main():
             "metric": METRIC, "value": round(total_images / dt_max, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_text(primary, B, HW),
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": workload_text(primary, B, HW, args.dtype),
                        "global_batch": B * world, "image_size": HW, "microbatch": args.microbatch,
                        "parallelism": f"image-sharded x{world}, one RCCL all-gather of per-image records per step (device buffers)",
                        "weights": "seeded synthetic checkpoints (no weight files offline)"},
-            "roofline": roofline(primary, args.steps, ev_ms, flops, flops_exec),
+            "roofline": roofline(primary, args.steps, ev_ms, flops, flops_exec, eng, args.dtype),
         }
     # sub-measurements (N = 1 only): BASELINE configs[1] and north_star's TOPIQ+CLIP target line, 3 timed steps each
     sub = {}
-    for wl in subs:
+    sub_runs = [(wl, wl, args.dtype) for wl in subs]
+    if "bf16" in engines and args.dtype == "f32":
+        sub_runs.append(("ensemble_bf16", "ensemble", "bf16"))      # BASELINE configs[3] on one GPU
+    for key, wl, dt in sub_runs:
         s_steps, s_warm = 3, 1
-        dts, evs, fl, fx = measure(wl, s_steps, s_warm)
-        sub[wl] = {"value": round(B * s_steps / dts, 2), "unit": "images/s", "steps": s_steps, "warmup": s_warm,
-                   "ms_per_step": round(dts / s_steps * 1e3, 3), "dtype": "f32",
-                   "config": {"workload": workload_text(wl, B, HW)},
-                   "roofline": roofline(wl, s_steps, evs, fl, fx)}
+        e = engines[dt]
+        dts, evs, fl, fx = measure(wl, s_steps, s_warm, e)
+        sub[key] = {"value": round(B * s_steps / dts, 2), "unit": "images/s", "steps": s_steps, "warmup": s_warm,
+                    "ms_per_step": round(dts / s_steps * 1e3, 3), "dtype": dt,
+                    "config": {"workload": workload_text(wl, B, HW, dt)},
+                    "roofline": roofline(wl, s_steps, evs, fl, fx, e, dt)}
     if rank == 0:
         if sub:
             out["sub"] = sub
@@ -379,7 +407,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.dev_free(d_imgs)
-    eng.close()
+    for e in engines.values():
+        e.close()
 
 
 if __name__ == "__main__":

@@ -4,13 +4,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from facet_amd import Engine
 from facet_amd._lib import FE_MODEL_CLIP, FE_MODEL_AESTHETIC
 from facet_amd.weights import synthetic_state_dict
-n, mb = 32, 32
-eng = Engine(0, arena_bytes=24 << 30)
+n, mb = 127, 32
+prec = 'bf16' if 'bf16' in sys.argv else 'f32'
+eng = Engine(0, arena_bytes=40 << 30, precision=prec)
 eng.set_microbatch(mb)
 x = np.random.default_rng(0).standard_normal((n, 3, 224, 224), dtype=np.float32)
 eng.load_weights(FE_MODEL_CLIP, synthetic_state_dict("clip", 9))
 d = eng.dev_alloc(x.nbytes); eng.h2d(d, x)
 eng.clip_encode_image((d, n))
+eng.timer_start(); eng.clip_encode_image((d, n)); ms = eng.timer_stop()
+print(f'{prec}: {n} images in {ms:.2f} ms = {n / ms * 1e3:.1f} img/s')
 eng.profile_enable(True)
 eng.clip_encode_image((d, n))
 recs = eng.profile_records(); eng.profile_enable(False)

@@ -9,8 +9,9 @@ from facet_amd.weights import synthetic_state_dict, synthetic_images
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 mb = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 hw = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
-level_only = len(sys.argv) > 4
-eng = Engine(0, arena_bytes=(4 + 2 * mb) << 30)
+level_only = len(sys.argv) > 4 and sys.argv[4] == "levels"
+prec = "bf16" if "bf16" in sys.argv else "f32"
+eng = Engine(0, arena_bytes=(4 + 2 * mb) << 30, precision=prec)
 eng.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", 3))
 imgs = synthetic_images(2, n, hw, hw)
 d = eng.dev_alloc(imgs.nbytes); eng.h2d(d, imgs)
