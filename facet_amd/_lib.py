@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfacet_engine.so")
+LIB_PATH = os.environ.get("FACET_AMD_LIB") or os.path.join(_HERE, "libfacet_engine.so")   # env: developer A/B builds only
 
 FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_SAMP, FE_MODEL_U2NETP, FE_MODEL_AESTHETIC = range(5)
 FE_MODEL_SCRFD, FE_MODEL_ARCFACE = 5, 6

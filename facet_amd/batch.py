@@ -16,7 +16,15 @@ narrower mapping of the single-pass path (batch_processor.py:272-296).
 
 Engine calls per batch: fe_ensemble_score (TOPIQ + CLIP + aesthetic + U2-Net-P + SAMP-Net), fe_image_stats (technical scans),
 fe_face_analyze + fe_roi_laplacian (through FaceAnalyzer.analyze_faces_batch), fe_tag_similarities (through CLIPTagger).
+
+Overlap: a context runs one call at a time (one arena, one stream), and the face / statistics / leading-lines calls spend most of
+their time in host glue (NMS, similarity transforms, Hough votes, percentile arithmetic) with the GPU idle. Give the scorer a second
+context on the same GPU (`aux_engine=`, and build the FaceAnalyzer on it): those calls then run on a worker thread beside
+fe_ensemble_score - ctypes drops the GIL, the hardware queues interleave the two streams - and the step costs max(models, rest)
+instead of their sum. Results are identical to the single-context path (tests/test_batch_gpu.py).
 """
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 from .aggregate import aggregate_batch
@@ -56,8 +64,16 @@ def detect_silhouette(histogram_silhouette, tags, face_count):
 
 class BatchScorer:
     def __init__(self, engine, tagger=None, face_analyzer=None, tag_threshold=0.22, max_tags=5, mono_threshold=0.10,
-                 shadow_threshold=0.15, highlight_threshold=0.10, power_weight=2.0, line_weight=1.0, policy=None, detect_lines=False):
+                 shadow_threshold=0.15, highlight_threshold=0.10, power_weight=2.0, line_weight=1.0, policy=None, detect_lines=False,
+                 aux_engine=None):
         self.engine, self.tagger, self.face_analyzer, self.policy, self.detect_lines = engine, tagger, face_analyzer, policy, detect_lines
+        # second context on the same GPU for statistics / faces / lines (see module docstring); None = everything on `engine`, in sequence
+        self.aux_engine = aux_engine
+        self._pool = ThreadPoolExecutor(max_workers=1) if aux_engine is not None else None
+        if aux_engine is not None and face_analyzer is not None and getattr(face_analyzer, "available", False):
+            fe = getattr(getattr(face_analyzer, "face_app", None), "engine", None)
+            if fe is not None and fe is engine:
+                raise ValueError("with aux_engine the FaceAnalyzer must be built on the aux engine (one call at a time per context)")
         self.power_weight, self.line_weight = power_weight, line_weight
         self.tag_threshold, self.max_tags = tag_threshold, max_tags           # utils/tags.py:50-51 defaults
         self.mono_threshold, self.shadow_threshold, self.highlight_threshold = mono_threshold, shadow_threshold, highlight_threshold
@@ -75,14 +91,27 @@ class BatchScorer:
             e.h2d(d_rgb, imgs)
             e.swap_rb(d_rgb, n * h * w, d_bgr)
             rgb_dev, bgr_dev = (d_rgb, n, h, w), (d_bgr, n, h, w)
-            rec, mask = e.ensemble_score(rgb_dev)
-            tech = TechnicalAnalyzer.analyze_batch(e, bgr_dev, self.shadow_threshold, self.highlight_threshold, self.mono_threshold)
-            faces = None
-            if self.face_analyzer is not None and self.face_analyzer.available:
-                faces = self.face_analyzer.analyze_faces_batch([imgs[i][..., ::-1] for i in range(n)], resident=bgr_dev)
-            if leading_lines is None and self.detect_lines:      # CompositionAnalyzer.detect_leading_lines (multi_pass.py:702-705), batched
-                from .composition import score_lines
-                leading_lines = [score_lines(l, h, w)['leading_lines_score'] for l in e.leading_lines(bgr_dev)]
+
+            def rest(eng):      # everything that is not a model of the ensemble; reads the BGR copy only
+                tech_ = TechnicalAnalyzer.analyze_batch(eng, bgr_dev, self.shadow_threshold, self.highlight_threshold, self.mono_threshold)
+                faces_ = None
+                if self.face_analyzer is not None and self.face_analyzer.available:
+                    faces_ = self.face_analyzer.analyze_faces_batch([imgs[i][..., ::-1] for i in range(n)], resident=bgr_dev)
+                lines_ = leading_lines
+                if lines_ is None and self.detect_lines:      # CompositionAnalyzer.detect_leading_lines (multi_pass.py:702-705), batched
+                    from .composition import score_lines
+                    lines_ = [score_lines(l, h, w)['leading_lines_score'] for l in eng.leading_lines(bgr_dev)]
+                return tech_, faces_, lines_
+
+            if self._pool is not None:
+                fut = self._pool.submit(rest, self.aux_engine)      # fe_swap_rb_u8 has synchronised: the BGR copy is complete
+                try:
+                    rec, mask = e.ensemble_score(rgb_dev)
+                finally:
+                    tech, faces, leading_lines = fut.result()       # also on error: the worker must be done before the buffers go
+            else:
+                rec, mask = e.ensemble_score(rgb_dev)
+                tech, faces, leading_lines = rest(e)
         finally:
             e.dev_free(d_rgb)
             e.dev_free(d_bgr)

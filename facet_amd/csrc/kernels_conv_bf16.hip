@@ -289,6 +289,22 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_bf16_kernel(
 #pragma unroll
       for (int e = 0; e < 8; ++e) sl[e] = (colb + e < p.Cout) ? p.slope[colb + e] : 0.f;
     }
+    // residual rows of ALL the wave's 32-row slabs are requested up front (TM * NIT <= 8 x 16 B per lane): the short-K layers that
+    // carry a residual are bound by their HBM streams, and this doubles the bytes in flight during the LDS transposes
+    constexpr bool RES_AHEAD = (TM * NIT <= 8);
+    uint4 rall[RES_AHEAD ? TM * NIT : 1];
+    if constexpr (RES_AHEAD) {
+      if (p.res) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int m = m0 + wm * TM * 32 + i * 32 + lr + it * RPI;
+            const int mc = m < p.M ? m : p.M - 1;
+            rall[i * NIT + it] = *reinterpret_cast<const uint4*>(p.res + (size_t)mc * p.ldr + colc);
+          }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -303,7 +319,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_bf16_kernel(
       for (int it = 0; it < NIT; ++it) {
         const int m = mrow0 + it * RPI;
         const int mc = m < p.M ? m : p.M - 1;
-        if (p.res) rv[it] = *reinterpret_cast<const uint4*>(p.res + (size_t)mc * p.ldr + colc);
+        if constexpr (RES_AHEAD) { if (p.res) rv[it] = rall[i * NIT + it]; }
+        else if (p.res) rv[it] = *reinterpret_cast<const uint4*>(p.res + (size_t)mc * p.ldr + colc);
         if (p.gate) {
           if (p.gate_c1) gs[it] = (float)p.gate[(size_t)mc * p.ldg];
           else gv[it] = *reinterpret_cast<const uint4*>(p.gate + (size_t)mc * p.ldg + colc);

@@ -97,31 +97,45 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
   int tap = 0, kh = 0, kw = 0, ci = 0;
   const int nk = p.Kp / BK;
 
-  auto issue = [&](int kt, int buf) {
-    float* Ab = smem + buf * SLAB;
-    float* Bb = Ab + BM * BK;
-    const int tb = ((kh * p.dh * p.W + kw * p.dw) * p.ldx + ci) * 4;   // byte offset of this tap/channel slab
-    {
-#pragma unroll
-      for (int j = 0; j < AI; ++j) {
-        if (16 * (4 * j + wave) < BM) {
-          const bool ok = ((amask[j] >> tap) & 1ull) && (ci < p.Cin);   // ci == Cin only in the zero-padded K tail
-          const unsigned off = ok ? aoffs[j] + (unsigned)tb : 0xFFFFFFF0u;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(Ab + 256 * (4 * j + wave)), 16, (int)off, 0, 0, 0);
-        }
+  // One K-slab = AI A-pieces + BI B-pieces per wave. issue_begin fixes the slab's addresses, issue_piece(q) launches one 1-KiB
+  // LDS-DMA, issue_end advances the tap state: the main loop spreads the pieces BETWEEN the MFMAs of the current slab, where their
+  // issue cost (address VALU + the VMEM issue slot, 60-185 cycles each) disappears in the shadow of the 64-cycle MFMAs.
+  float* iAb = nullptr; float* iBb = nullptr;
+  int i_tb = 0, i_tbb2 = 0;
+  bool i_cin_ok = true;
+  auto issue_begin = [&](int kt, int buf) {
+    iAb = smem + buf * SLAB;
+    iBb = iAb + BM * BK;
+    i_tb = ((kh * p.dh * p.W + kw * p.dw) * p.ldx + ci) * 4;   // byte offset of this tap/channel slab
+    i_tbb2 = kt * (BK * 4);
+    i_cin_ok = ci < p.Cin;                                       // ci == Cin only in the zero-padded K tail
+  };
+  auto issue_piece = [&](int q) {      // q < AI: A piece q; else B piece q - AI  (q is a compile-time constant at every call site)
+    if (q < AI) {
+      const int j = q;
+      if (16 * (4 * j + wave) < BM) {
+        const bool ok = ((amask[j] >> tap) & 1ull) && i_cin_ok;
+        const unsigned off = ok ? aoffs[j] + (unsigned)i_tb : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(iAb + 256 * (4 * j + wave)), 16, (int)off, 0, 0, 0);
       }
-      const int tbb2 = kt * (BK * 4);
-#pragma unroll
-      for (int j = 0; j < BI; ++j) {
-        if (16 * (4 * j + wave) < BN)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(Bb + 256 * (4 * j + wave)), 16, (int)boffs[j], tbb2, 0, 0);
-      }
-      // K order: 16-channel block outer, tap inner - the 9 taps of a 3x3 re-read the same input rows back to back,
-      // so the re-reads hit L1/L2 instead of coming back from the Infinity Cache a third of a K-loop later.
-      ++tap;
-      if (++kw == p.KW) { kw = 0; ++kh; }
-      if (tap == ntaps) { tap = 0; kh = 0; kw = 0; ci += BK; }
+    } else {
+      const int j = q - AI;
+      if (16 * (4 * j + wave) < BN)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(iBb + 256 * (4 * j + wave)), 16, (int)boffs[j], i_tbb2, 0, 0);
     }
+  };
+  auto issue_end = [&]() {
+    // K order: 16-channel block outer, tap inner - the 9 taps of a 3x3 re-read the same input rows back to back,
+    // so the re-reads hit L1/L2 instead of coming back from the Infinity Cache a third of a K-loop later.
+    ++tap;
+    if (++kw == p.KW) { kw = 0; ++kh; }
+    if (tap == ntaps) { tap = 0; kh = 0; kw = 0; ci += BK; }
+  };
+  auto issue = [&](int kt, int buf) {
+    issue_begin(kt, buf);
+#pragma unroll
+    for (int q = 0; q < AI + BI; ++q) issue_piece(q);
+    issue_end();
   };
 
   f32x16 acc[TM][TN];
@@ -163,6 +177,10 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
     }
   };
   const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
+#ifndef FE_DMA_SPREAD
+#define FE_DMA_SPREAD 1     // build-time A/B hook: 0 = all pieces of a slab issued in front of the MFMA burst (round-1 form)
+#endif
+  constexpr bool spread_issue = FE_DMA_SPREAD != 0;
   v4f fa[2][2 * TM], fb[2][2 * TN];   // [register set][fragment]; indices are compile-time everywhere below
 #define FE_READ_FRAGS(SET, SLOT)                                                                                   \
   {                                                                                                                \
@@ -185,18 +203,48 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i + hh].z, fb[SET][2 * j + hh].z, acc[i][j], 0, 0, 0); \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i + hh].w, fb[SET][2 * j + hh].w, acc[i][j], 0, 0, 0); \
       }
+  // The same burst with this wave's DMA pieces of slab kt+3 spread between its MFMA quads (DO: block-uniform, false in the tail).
+  // Quad q = the four k-slots of one (hh, i, j); piece n goes behind quad max(0, (n + 1) * Q / (NP + 1) - 1) (always < Q). sched_barrier pins the order:
+  // hipcc otherwise gathers the loads in front of the MFMAs again.
+#define FE_MFMA_BURST_ISSUE(SET, DO)                                                                               \
+  {                                                                                                                \
+    constexpr int Q_ = 2 * TM * TN, NP_ = AI + BI;                                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < Q_; ++q_) {                                                            \
+      const int hh = q_ / (TM * TN), i = (q_ / TN) % TM, j = q_ % TN;                                              \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i + hh].x, fb[SET][2 * j + hh].x, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i + hh].y, fb[SET][2 * j + hh].y, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i + hh].z, fb[SET][2 * j + hh].z, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i + hh].w, fb[SET][2 * j + hh].w, acc[i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int n_ = 0; n_ < NP_; ++n_)                                                           \
+        if (((n_ + 1) * Q_ / (NP_ + 1) - 1 < 0 ? 0 : (n_ + 1) * Q_ / (NP_ + 1) - 1) == q_) {                       \
+          __builtin_amdgcn_sched_barrier(0);                                                                       \
+          if (DO) issue_piece(n_);                                                                                 \
+          __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                          \
+    }                                                                                                              \
+  }
   // one K-step: fragments of slab kt are in register set CUR
 #define FE_STEP(CUR, NXT, KT)                                                                                      \
   {                                                                                                                \
     const int kt_ = (KT);                                                                                          \
+    bool do_issue_ = false;                                                                                        \
     if (kt_ + 1 < nk) {                                                                                            \
       wait_vm(kt_ + 2 < nk ? npw : 0);                                                                             \
       __builtin_amdgcn_s_barrier();                                                                                \
-      if (kt_ + 3 < nk) issue(kt_ + 3, kt_ % 3);                                                                   \
+      do_issue_ = kt_ + 3 < nk;                                                                                    \
+      if (do_issue_) {                                                                                             \
+        if constexpr (spread_issue) issue_begin(kt_ + 3, kt_ % 3);                                                 \
+        else issue(kt_ + 3, kt_ % 3);                                                                              \
+      }                                                                                                            \
       FE_READ_FRAGS(NXT, (kt_ + 1) % 3)                                                                            \
     }                                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
-    FE_MFMA_BURST(CUR)                                                                                             \
+    if constexpr (spread_issue) {                                                                                  \
+      FE_MFMA_BURST_ISSUE(CUR, do_issue_)                                                                          \
+      if (do_issue_) issue_end();                                                                                  \
+    } else {                                                                                                       \
+      FE_MFMA_BURST(CUR)                                                                                           \
+    }                                                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
   }
@@ -229,6 +277,7 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
     }
   }
 #undef FE_STEP
+#undef FE_MFMA_BURST_ISSUE
 #undef FE_MFMA_BURST
 #undef FE_READ_FRAGS
   __syncthreads();   // all fragment reads retired before the epilogue reuses the slabs as staging
@@ -244,6 +293,23 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + colc);
     if (p.shift) sf = *reinterpret_cast<const float4*>(p.shift + colc);
+    // Narrow wave tiles (TN = 1: the 128x64 / 256x32 / 64x64 blocks that carry the HBM-bound short-K layers) fetch the residual
+    // rows of ALL their 32-row slabs up front: TM * NIT <= 8 float4 per lane, twice the bytes in flight while the accumulators
+    // go through the LDS transpose. Wider tiles load per slab (their registers are taken by the accumulators).
+    constexpr bool RES_AHEAD = (TM * NIT <= 8);
+    float4 rall[RES_AHEAD ? TM * NIT : 1];
+    if constexpr (RES_AHEAD) {
+      if (p.res) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int m = m0 + wm * TM * 32 + i * 32 + lr + it * RPI;
+            const int mc = m < p.M ? m : p.M - 1;
+            rall[i * NIT + it] = *reinterpret_cast<const float4*>(p.res + (size_t)mc * p.ldr + colc);
+          }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -256,7 +322,8 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
       for (int it = 0; it < NIT; ++it) {
         const int m = mrow0 + it * RPI;
         const int mc = m < p.M ? m : p.M - 1;
-        if (p.res) rv[it] = *reinterpret_cast<const float4*>(p.res + (size_t)mc * p.ldr + colc);
+        if constexpr (RES_AHEAD) { if (p.res) rv[it] = rall[i * NIT + it]; }
+        else if (p.res) rv[it] = *reinterpret_cast<const float4*>(p.res + (size_t)mc * p.ldr + colc);
         if (p.gate) {
           if (p.gate_c1) { const float g = p.gate[(size_t)mc * p.ldg]; gv[it] = make_float4(g, g, g, g); }
           else gv[it] = *reinterpret_cast<const float4*>(p.gate + (size_t)mc * p.ldg + colc);

@@ -92,3 +92,36 @@ def test_process_batch_equals_per_model_calls():
         assert r['composition_pattern'] in ('global', 'horizontal', 'vertical', 'triangular', 'surround', 'quarter', 'cross', 'rule_of_thirds')
     fa.face_app.unload()
     e.close()
+
+
+def test_aux_engine_overlap_gives_identical_dicts():
+    """BatchScorer(aux_engine=...) runs statistics / faces / leading lines on a second context beside fe_ensemble_score: every
+    value of every dict must equal the single-context result."""
+    from facet_amd import Engine
+    e, e2 = Engine(0, arena_bytes=10 << 30), Engine(0, arena_bytes=6 << 30)
+    for mid, name in ((FE_MODEL_TOPIQ, "topiq"), (FE_MODEL_CLIP, "clip"), (FE_MODEL_AESTHETIC, "aesthetic"), (FE_MODEL_U2NETP, "u2netp"), (FE_MODEL_SAMP, "samp_net")):
+        e.load_weights(mid, synthetic_state_dict(name, 4))
+    models = {"det": S.scrfd_like(seed=12, size=320)[0], "lmk": S.landmark_like(seed=13)[0], "rec": S.arcface_iresnet(layers=(1, 1, 1, 1), seed=14)[0]}
+    fas = []
+    for eng in (e, e2):
+        fa = FaceAnalyzer(min_confidence=0.55, min_face_size=10, engine=eng, models=models)
+        fa.face_app.det_size, fa.face_app.max_candidates, fa.face_app.max_faces = (320, 320), 4096, 64
+        fas.append(fa)
+    imgs = synthetic_images(6, 7, 224, 256)
+    one = BatchScorer(e, face_analyzer=fas[0], detect_lines=True).process_batch(imgs)
+    with pytest.raises(ValueError):
+        BatchScorer(e, face_analyzer=fas[0], aux_engine=e2)          # the analyzer must live on the aux context
+    two = BatchScorer(e, face_analyzer=fas[1], detect_lines=True, aux_engine=e2).process_batch(imgs)
+    assert len(one) == len(two) == 7
+    for a, b in zip(one, two):
+        assert a.keys() == b.keys()
+        for k in a:
+            if k == 'face_details':
+                assert len(a[k]) == len(b[k])
+                continue
+            va, vb = a[k], b[k]
+            if isinstance(va, np.ndarray):
+                assert np.array_equal(va, vb), k
+            else:
+                assert va == vb, (k, va, vb)
+    e2.close(); e.close()

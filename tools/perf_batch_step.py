@@ -13,12 +13,15 @@ from facet_amd.weights import synthetic_state_dict, synthetic_images
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 hw = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-e = Engine(0)
+e = Engine(0, arena_bytes=72 << 30)
+e2 = Engine(0, arena_bytes=24 << 30)      # second context: statistics / faces / lines run beside the ensemble (BatchScorer aux_engine)
 for mid, name in ((FE_MODEL_TOPIQ, "topiq"), (FE_MODEL_CLIP, "clip"), (FE_MODEL_AESTHETIC, "aesthetic"), (FE_MODEL_U2NETP, "u2netp"), (FE_MODEL_SAMP, "samp_net")):
     e.load_weights(mid, synthetic_state_dict(name, 4))
 models = {"det": S.scrfd_like(seed=12, size=640)[0], "lmk": S.landmark_like(seed=13)[0], "rec": S.arcface_iresnet(layers=(3, 4, 14, 3), seed=14)[0]}
 fa = FaceAnalyzer(min_confidence=0.5, min_face_size=10, engine=e, models=models)
 fa.face_app.max_faces = 8
+fa2 = FaceAnalyzer(min_confidence=0.5, min_face_size=10, engine=e2, models=models)
+fa2.face_app.max_faces = 8
 vocab = {f"tag{i}": [f"p{i}a", f"p{i}b"] for i in range(40)}
 tg = CLIPTagger(config=types.SimpleNamespace(get_tag_vocabulary=lambda: vocab, get_art_tags=lambda: set()))
 names = [t for t, d in vocab.items() for _ in d]
@@ -37,12 +40,16 @@ for i in range(n):
         im[t:t + 4, 40:hw - 40] += 90
         im[40:hw - 40, t:t + 4] -= 60
     photo[i] = np.clip(im, 0, 255)
-for label, kw in (("models+stats+faces+tags+aggregate", dict(policy=pol)), ("... + leading lines", dict(policy=pol, detect_lines=True))):
-    bs = BatchScorer(e, tagger=tg, face_analyzer=fa, **kw)
+e.set_microbatch(32)
+for label, kw in (("one context: models+stats+faces+tags+aggregate", dict(policy=pol, face_analyzer=fa)),
+                  ("two contexts (aux_engine): models || stats+faces, +tags+aggregate", dict(policy=pol, face_analyzer=fa2, aux_engine=e2)),
+                  ("one context ... + leading lines", dict(policy=pol, detect_lines=True, face_analyzer=fa)),
+                  ("two contexts ... + leading lines", dict(policy=pol, detect_lines=True, face_analyzer=fa2, aux_engine=e2))):
+    bs = BatchScorer(e, tagger=tg, **kw)
     bs.process_batch(imgs[:8])
     for kind, batch in (("noise images", imgs), ("photo-like images", photo)):
         t0 = time.time(); out = bs.process_batch(batch); dt = time.time() - t0
         print(f"{label}, {kind}: {n} x {hw}x{hw}: {dt*1e3:.0f} ms = {n/dt:.1f} images/s   faces/img {np.mean([r['face_count'] for r in out]):.2f}", flush=True)
 pr = cProfile.Profile(); pr.enable(); bs.process_batch(imgs); pr.disable()
 st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(22); print(st.getvalue()[:4500])
-fa.face_app.unload(); e.close()
+fa.face_app.unload(); fa2.face_app.unload(); e2.close(); e.close()
