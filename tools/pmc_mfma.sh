@@ -1,12 +1,17 @@
 #!/bin/bash
-# Matrix-core utilisation of the default bench workload from one PMC pass (SQ counters only, with --kernel-trace as the pool requires):
-#   SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per kernel -> profiles/pmc/r01_topiq_mfma_busy.summary.txt
+# Matrix-core utilisation of a bench workload from one PMC pass -> gpurun_out/<tag>_<workload>[_bf16]_mfma_busy.summary.txt
+# usage: tools/pmc_mfma.sh <workload> [f32|bf16]
+# Counter budget (MI355X_MICROARCH.md, rocprofv3 PMC slots): SQ has 8 slots per pass, GRBM 2, independent of each other - this pass takes
+# 4 SQ counters + 1 GRBM counter and nothing from TCC; it runs with --kernel-trace only (no other trace domain beside --pmc).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 WL=${1:-topiq}
+DT=${2:-f32}
+TAG=${ROUND_TAG:-r02}
+KEY=$WL; [ "$DT" = bf16 ] && KEY=${WL}_bf16
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_mfma
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma -- python3 $R/bench.py --workload $WL --steps 1 --warmup 1 --batch 32 --cpu-sample 0 > $R/gpurun_out/pmc_mfma.log 2>&1 || { echo "pass failed"; tail -5 $R/gpurun_out/pmc_mfma.log; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma -- python3 $R/bench.py --workload $WL --dtype $DT --steps 1 --warmup 1 --batch 32 --cpu-sample 0 --no-sub > $R/gpurun_out/pmc_mfma.log 2>&1 || { echo "pass failed"; tail -5 $R/gpurun_out/pmc_mfma.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$R/gpurun_out/pmc_mfma/*/*counter_collection.csv")[0]
@@ -26,17 +31,18 @@ tot_g = sum(v["GRBM_GUI_ACTIVE"] for _, v in rows)
 import json, re
 line = [l for l in open("$R/gpurun_out/pmc_mfma.log") if l.startswith("{")][-1]
 bench = json.loads(line)
-exec_flops = bench["roofline"]["executed_flops_per_image"] * (96 if "$WL" == "topiq" else 64)   # passes of 32 images: warm-up, timed (+ per-launch for topiq)
-expect_simd_cycles = exec_flops / 4096 * 64
-out = ["# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -- python3 bench.py --workload $WL --steps 1 --warmup 1 --batch 32 --cpu-sample 0",
+exec_flops = bench["roofline"]["executed_flops_per_image"] * 96      # three passes of 32 images: warm-up, timed, per-launch profile
+# one v_mfma_f32_32x32x2_f32 = 4096 FLOP and 64 cycles of its SIMD's pipe; one v_mfma_f32_32x32x16_bf16 = 32768 FLOP and 32 cycles
+expect_simd_cycles = exec_flops / 32768 * 32 if "$DT" == "bf16" else exec_flops / 4096 * 64
+out = ["# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -- python3 bench.py --workload $WL --dtype $DT --steps 1 --warmup 1 --batch 32 --cpu-sample 0 --no-sub",
        "# per kernel (summed over launches): launches, share of elapsed cycles, matrix pipes busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8) / 1024 SIMDs, issue-stall share SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES",
-       f"# whole run: sum SQ_VALU_MFMA_BUSY_CYCLES {tot_m:.4g}; MFMA instructions x 64 cycles from the engine's FLOP counter {expect_simd_cycles:.4g} (ratio {tot_m / expect_simd_cycles:.3f});",
+       f"# whole run: sum SQ_VALU_MFMA_BUSY_CYCLES {tot_m:.4g}; MFMA pipe cycles implied by the engine's executed-FLOP counter {expect_simd_cycles:.4g} (ratio {tot_m / expect_simd_cycles:.3f});",
        f"#            elapsed shader cycles of all launches (GRBM_GUI_ACTIVE / 8) {tot_g / 8:.4g} -> matrix pipes busy {tot_m / (tot_g / 8) / 1024:.3f} of the elapsed cycles"]
 for k, v in rows[:14]:
     b = v["SQ_BUSY_CYCLES"]
     g = max(v["GRBM_GUI_ACTIVE"] / 8, 1)
     out.append(f"{k[:70]:70s} x{calls[k]:4d}  {v['GRBM_GUI_ACTIVE'] / tot_g * 100:5.1f} % of cycles   matrix pipes busy {v['SQ_VALU_MFMA_BUSY_CYCLES'] / g / 1024:.3f} (of 1024)   issue-stall {v['SQ_WAIT_INST_ANY'] / max(v['SQ_WAVE_CYCLES'], 1):.3f}")
-open("$R/gpurun_out/r01_${WL}_mfma_busy.summary.txt", "w").write("\n".join(out) + "\n")
+open("$R/gpurun_out/${TAG}_${KEY}_mfma_busy.summary.txt", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
 PY
 find $R/gpurun_out/pmc_mfma -name "*kernel_trace.csv" -delete

@@ -1,15 +1,21 @@
 #!/bin/bash
-# HBM traffic (PMC FETCH_SIZE / WRITE_SIZE, separate passes) of the bench workloads -> profiles/r01_traffic.json
+# HBM traffic (PMC FETCH_SIZE / WRITE_SIZE) of bench workloads -> profiles/r02_traffic.json (key: workload, or workload_bf16).
+# usage: tools/traffic_all.sh <workload>[:bf16] ...      e.g.  tools/traffic_all.sh full topiq ensemble:bf16
+# Counter budget (MI355X_MICROARCH.md, rocprofv3 PMC slots): the TCC block has 4 slots per pass, FETCH_SIZE takes 3 and WRITE_SIZE 2, so
+# they cannot share a pass: ONE counter per pass, each pass its own run, --kernel-trace only beside --pmc (what the pool accepts).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${ROUND_TAG:-r02}
 cd /tmp && export TMPDIR=/tmp
-for wl in "$@"; do
+for spec in "$@"; do
+  wl=${spec%%:*}; dt=f32; [ "$spec" != "$wl" ] && dt=${spec##*:}
+  key=$wl; [ "$dt" = bf16 ] && key=${wl}_bf16
   for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf $R/gpurun_out/pmc_${wl}_$c
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${wl}_$c -- python3 $R/bench.py --workload $wl --steps 1 --warmup 1 --batch 32 --cpu-sample 0 > $R/gpurun_out/pmc_${wl}_$c.log 2>&1 || { echo "pass $wl $c failed"; tail -3 $R/gpurun_out/pmc_${wl}_$c.log; exit 1; }
-    echo "done $wl $c"
+    rm -rf $R/gpurun_out/pmc_${key}_$c
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${key}_$c -- python3 $R/bench.py --workload $wl --dtype $dt --steps 1 --warmup 1 --batch 32 --cpu-sample 0 --no-sub > $R/gpurun_out/pmc_${key}_$c.log 2>&1 || { echo "pass $key $c failed"; tail -3 $R/gpurun_out/pmc_${key}_$c.log; exit 1; }
+    echo "done $key $c"
   done
-  n=64; [ "$wl" = topiq ] && n=96   # bench.py appends a 32-image per-launch pass for the topiq workload
-  python3 $R/tools/collect_traffic.py $R/gpurun_out/pmc_${wl}_FETCH_SIZE $R/gpurun_out/pmc_${wl}_WRITE_SIZE $n $wl 1024 && cp $R/profiles/r01_traffic.json $R/gpurun_out/r01_traffic.json
-  find $R/gpurun_out/pmc_${wl}_FETCH_SIZE $R/gpurun_out/pmc_${wl}_WRITE_SIZE -name "*kernel_trace.csv" -delete
+  # images the run pushed through the models: warm-up step + timed step + the per-launch profile pass, 32 each
+  python3 $R/tools/collect_traffic.py $R/gpurun_out/pmc_${key}_FETCH_SIZE $R/gpurun_out/pmc_${key}_WRITE_SIZE 96 $key 1024 $TAG "--workload $wl --dtype $dt" && cp $R/profiles/${TAG}_traffic.json $R/gpurun_out/${TAG}_traffic.json
+  find $R/gpurun_out/pmc_${key}_FETCH_SIZE $R/gpurun_out/pmc_${key}_WRITE_SIZE -name "*kernel_trace.csv" -delete
 done
