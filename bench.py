@@ -85,7 +85,7 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
         from PIL import Image
         from oracle.sampnet import U2NETP, SAMPNet
         from oracle import face_ref
-        from facet_amd import synthetic_onnx as SO
+        from standins import synthetic_onnx as SO
         u2, sn = ld(U2NETP(), "u2netp"), ld(SAMPNet(), "samp_net")
         im_m, im_s = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
         fm = {"det": (SO.scrfd_like(seed=12, size=640)[0], 127.5, 128.0), "lmk": (SO.landmark_like(seed=13)[0], 0.0, 1.0),
@@ -264,7 +264,7 @@ def main():
             # BASELINE.json configs[2] / the metric's InsightFace stage. Seeded stand-in graphs of the buffalo_l architectures
             # (no model files offline); uniform-noise images carry no real faces, so the best FACES_PER_IMAGE detections of the
             # synthetic detector go through landmarks + ArcFace (fixed faces-per-image mode).
-            from facet_amd import synthetic_onnx as SO
+            from standins import synthetic_onnx as SO
             from facet_amd._lib import FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC
             e.graph_load(FE_GRAPH_FACE_DET, SO.scrfd_like(seed=12, size=640)[0])
             e.graph_load(FE_GRAPH_FACE_LMK, SO.landmark_like(seed=13)[0])

@@ -51,6 +51,24 @@ __device__ __forceinline__ float fe_apply_act(float v, int act) {
   return v;
 }
 
+// erf for epilogues whose result is rounded to bf16 anyway: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 (bf16 keeps 2^-9
+// relative), one v_exp + one v_rcp + 6 FMAs instead of libm's branchy erff - the GELU of a 4096-wide ViT MLP layer otherwise costs
+// as many cycles as its K = 1024 main loop on the bf16 matrix cores.
+__device__ __forceinline__ float fe_erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float y = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+__device__ __forceinline__ float fe_apply_act_fast(float v, int act) {   // bf16 epilogues only
+  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == ACT_GELU) return 0.5f * v * (1.f + fe_erf_fast(v * 0.70710678118654752440f));
+  if (act == ACT_SIGMOID) return __frcp_rn(1.f + __expf(-v));
+  if (act == ACT_SOFTPLUS) return v > 20.f ? v : log1pf(expf(v));
+  return v;
+}
+
 // bf16 storage type of the reduced-precision path (BASELINE configs[3]). hipcc lowers float <-> __bf16 casts to
 // v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN) / a 16-bit shift.
 typedef __bf16 bf16;

@@ -9,8 +9,8 @@
 //   * a K "slab" is 32 bf16 = 64 B per row, moved HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB = 16 rows per wave
 //     instruction); lane-linear LDS image with the XOR swizzle applied on the SOURCE side and mirrored in the ds_read_b128 address;
 //   * one ds_read_b128 = 8 bf16 = a lane's whole A (or B) fragment of one 32x32x16 MFMA (lane (r, h): k = 8h .. 8h+7): 2 MFMAs per
-//     32x32 tile and slab, so a K-step takes KB = 2 slabs (16 MFMAs per wave and barrier for 64x64 wave tiles);
-//   * 3-step LDS ring, counted vmcnt, one raw s_barrier per K-step, register double-buffered fragments (inline-asm ds_read so hipcc
+//     32x32 tile and slab; the slab's DMA pieces for three slabs ahead are issued between those MFMAs;
+//   * 3-slab LDS ring, counted vmcnt, one raw s_barrier per slab, register double-buffered fragments (inline-asm ds_read so hipcc
 //     does not drain the DMA ring in front of every LDS read);
 //   * K order of the packed weights / the implicit im2col: channel block (cb = 32, or 16 when Cin % 32 != 0) outer, tap inner,
 //     channel-in-block innermost. With cb = 16 a slab holds TWO (block, tap) units: lanes pick theirs by the half of the slab
@@ -41,12 +41,13 @@ __device__ __forceinline__ void h_unpack8(const uint4 u, float v[8]) {
 }
 
 // UNITS = 32 / cb: (channel block, tap) units per 32-element slab. MODE 0 plain, 2 PReLU epilogue.
-template <int WGM, int WGN, int TM, int TN, int UNITS, int KB, int MODE = 0>   // KB: slabs per K-step (barrier interval)
-__global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_bf16_kernel(ConvParamsH p, const int ntiles) {
+// ONE_TAP: 1x1 kernels (GEMMs) - no tap masks, the K offset of a slab goes into the scalar offset of the buffer load.
+template <int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? (WGM * TM * 32 % 64 == 0 && WGN * TN * 32 % 64 == 0 ? 3 : 2) : 3)) void conv_bf16_kernel(ConvParamsH p, const int ntiles) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int AI = (BM + 63) / 64, BI = (BN + 63) / 64;    // DMA pieces per wave per slab (16 rows x 64 B each)
   constexpr int SLAB = (BM + BN) * 64;                       // bytes per slab
-  constexpr int STEP = KB * SLAB;                            // bytes per ring entry
+  constexpr int STEP = SLAB;                                 // bytes per ring entry (one slab per barrier: see launch_conv_bf16)
   static_assert(WGM * WGN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem_h[];
 
@@ -128,39 +129,50 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_bf16_kernel(
     }
   };
   const int nsub = p.Kp / 32;            // slabs; Kp % 64 == 0
-  const int nsteps = nsub / KB;
+  const int nsteps = nsub;
 
-  auto issue_slab = [&](int g, char* base) {
-    char* Ab = base;
-    char* Bb = base + BM * 64;
+  // One slab = AI A-pieces + BI B-pieces per wave. issue_begin fixes the slab's addresses, issue_piece(q) launches one 1-KiB LDS-DMA,
+  // issue_end advances the unit state: the main loop spreads the pieces BETWEEN the MFMAs of the current slab (a piece costs its wave
+  // 60-185 cycles of issue, an MFMA occupies the pipe for 32: issued in front of the burst the pieces took longer than the burst).
+  char* iAb = nullptr; char* iBb = nullptr;
+  int i_tb = 0, i_tap = 0, i_tbb = 0;
+  bool i_cok = true;
+  auto issue_begin = [&](int g) {
+    iAb = smem_h + (g % 3) * STEP;
+    iBb = iAb + BM * 64;
     const int tb0 = ((kh0 * p.dh * p.W + kw0 * p.dw) * p.ldx + ci0) * 2;
-    int tb = tb0, tapl = tap0, cil = ci0;
+    int cil = ci0;
+    i_tb = tb0; i_tap = tap0;
     if (UNITS == 2) {
       const int tb1 = ((kh1 * p.dh * p.W + kw1 * p.dw) * p.ldx + ci1) * 2;
-      tb = upar ? tb1 : tb0; tapl = upar ? tap1 : tap0; cil = upar ? ci1 : ci0;
+      i_tb = upar ? tb1 : tb0; i_tap = upar ? tap1 : tap0; cil = upar ? ci1 : ci0;
     }
-    const bool cok = (cil + cofs) < p.Cin;   // chunk inside the channel range (the K tail and 1x1 kernels with Cin % 32 != 0)
-#pragma unroll
-    for (int j = 0; j < AI; ++j) {
+    i_cok = (cil + cofs) < p.Cin;   // chunk inside the channel range (the K tail and 1x1 kernels with Cin % 32 != 0)
+    i_tbb = g * 64;
+  };
+  auto issue_piece = [&](int q) {      // q < AI: A piece q; else B piece q - AI (q is a compile-time constant at every call site)
+    if (q < AI) {
+      const int j = q;
       if (16 * (4 * j + wave) < BM) {
-        const bool ok = ((amask[j] >> tapl) & 1ull) && cok;
-        const unsigned off = ok ? aoffs[j] + (unsigned)tb : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(Ab + 1024 * (4 * j + wave)), 16, (int)off, 0, 0, 0);
+        const bool ok = ((amask[j] >> i_tap) & 1ull) && i_cok;
+        const unsigned off = ok ? aoffs[j] + (unsigned)i_tb : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(iAb + 1024 * (4 * j + wave)), 16, (int)off, 0, 0, 0);
       }
-    }
-    const int tbb = g * 64;
-#pragma unroll
-    for (int j = 0; j < BI; ++j) {
+    } else {
+      const int j = q - AI;
       if (16 * (4 * j + wave) < BN)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(Bb + 1024 * (4 * j + wave)), 16, (int)boffs[j], tbb, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(iBb + 1024 * (4 * j + wave)), 16, (int)boffs[j], i_tbb, 0, 0);
     }
+  };
+  auto issue_end = [&]() {
     advance(tap0, kh0, kw0, ci0);
     if (UNITS == 2) advance(tap1, kh1, kw1, ci1);
   };
-  auto issue_step = [&](int st) {
-    char* base = smem_h + (st % 3) * STEP;
+  auto issue_step = [&](int st) {      // whole slab at once (prologue)
+    issue_begin(st);
 #pragma unroll
-    for (int s = 0; s < KB; ++s) issue_slab(st * KB + s, base + s * SLAB);
+    for (int q = 0; q < AI + BI; ++q) issue_piece(q);
+    issue_end();
   };
 
   h_f32x16 acc[TM][TN];
@@ -179,7 +191,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_bf16_kernel(
   // pieces per wave per K-step (for the counted waits)
   const int npw1 = (BM / 64) + ((16 * wave < BN) ? 1 : 0) + ((BN > 64 && 16 * (4 + wave) < BN) ? 1 : 0);
   static_assert(BM % 64 == 0 && BN <= 128, "A pieces uniform over waves; B at most two pieces per wave");
-  const int npw = KB * npw1;
+  const int npw = npw1;
   auto wait_vm = [&](int n) {   // n is wave-uniform
     switch (n) {
       case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_bf16_kernel(
   h_v4f fa[2][2 * TM], fb[2][2 * TN];   // [register set][fragment]; indices are compile-time everywhere below
 #define FH_READ_FRAGS(SET, G)                                                                                        \
   {                                                                                                                  \
-    const unsigned sb_ = lds_base + (unsigned)((((G) / KB) % 3) * STEP + ((G) % KB) * SLAB);                         \
+    const unsigned sb_ = lds_base + (unsigned)(((G) % 3) * STEP);                         \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                 \
       asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET][2 * i]) : "v"(sb_ + (unsigned)(aoff + i * 32 * 64 + fo0)));      \
       asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET][2 * i + 1]) : "v"(sb_ + (unsigned)(aoff + i * 32 * 64 + fo1)));  \
@@ -211,35 +223,182 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_bf16_kernel(
       asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET][2 * j + 1]) : "v"(sb_ + (unsigned)(boff + j * 32 * 64 + fo1)));  \
     }                                                                                                                \
   }
-#define FH_MFMA_BURST(SET)                                                                                           \
-  _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                                                                   \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                   \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                               \
-        H8 a_, b_;                                                                                                   \
-        a_.f = fa[SET][2 * i + hh]; b_.f = fb[SET][2 * j + hh];                                                      \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i][j], 0, 0, 0);                         \
-      }
-  // one slab: fragments of slab g are in register set CUR; slab g+1 is read into NXT under the MFMAs of g. Entering a new
-  // K-step (ring entry) first waits for this wave's DMA pieces of that step, then one barrier publishes it (and retires every
-  // wave's reads of the step before it, whose buffer the next issue overwrites).
+  // MFMA burst of one slab with this wave's DMA pieces of slab g+3 spread between the MFMAs (DO: block-uniform, false in the tail).
+  // Piece n goes behind MFMA max(0, (n + 1) * Q / (NP + 1) - 1); sched_barrier pins the order (hipcc otherwise gathers the loads in
+  // front of the MFMAs again).
+#define FH_MFMA_BURST_ISSUE(SET, DO)                                                                                 \
+  {                                                                                                                  \
+    constexpr int Q_ = 2 * TM * TN, NP_ = AI + BI;                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < Q_; ++q_) {                                                              \
+      const int hh = q_ / (TM * TN), i = (q_ / TN) % TM, j = q_ % TN;                                                \
+      H8 a_, b_;                                                                                                     \
+      a_.f = fa[SET][2 * i + hh]; b_.f = fb[SET][2 * j + hh];                                                        \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i][j], 0, 0, 0);                           \
+      _Pragma("unroll") for (int n_ = 0; n_ < NP_; ++n_)                                                             \
+        if (((n_ + 1) * Q_ / (NP_ + 1) - 1 < 0 ? 0 : (n_ + 1) * Q_ / (NP_ + 1) - 1) == q_) {                         \
+          __builtin_amdgcn_sched_barrier(0);                                                                         \
+          if (DO) issue_piece(n_);                                                                                   \
+          __builtin_amdgcn_sched_barrier(0);                                                                         \
+        }                                                                                                            \
+    }                                                                                                                \
+  }
+  // one slab: fragments of slab g are in register set CUR; slab g+1 is read into NXT under the MFMAs of g. Entering slab g+1 first
+  // waits for this wave's DMA pieces of it, then one barrier publishes it (and retires every wave's reads of slab g, whose buffer
+  // the pieces issued during this burst overwrite).
 #define FH_SLAB(CUR, NXT, G)                                                                                         \
   {                                                                                                                  \
     const int g_ = (G);                                                                                              \
+    bool do_issue_ = false;                                                                                          \
     if (g_ + 1 < nsub) {                                                                                             \
-      if ((g_ + 1) % KB == 0) {                                                                                      \
-        const int st_ = (g_ + 1) / KB;                                                                               \
-        wait_vm(st_ + 1 < nsteps ? npw : 0);                                                                         \
-        __builtin_amdgcn_s_barrier();                                                                                \
-        if (st_ + 2 < nsteps) issue_step(st_ + 2);                                                                   \
-      }                                                                                                              \
+      wait_vm(g_ + 2 < nsub ? npw : 0);                                                                              \
+      __builtin_amdgcn_s_barrier();                                                                                  \
+      do_issue_ = g_ + 3 < nsub;                                                                                     \
+      if (do_issue_) issue_begin(g_ + 3);                                                                            \
       FH_READ_FRAGS(NXT, g_ + 1)                                                                                     \
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
-    FH_MFMA_BURST(CUR)                                                                                               \
+    FH_MFMA_BURST_ISSUE(CUR, do_issue_)                                                                              \
+    if (do_issue_) issue_end();                                                                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   }
 
+  // Tiles whose waves all issue the same number of pieces (BM, BN multiples of 64) take the LEAN loop: the generic one spends ~125
+  // instructions per slab and wave (scalar branches around every piece, a switch for the counted wait, modulo-3 ring arithmetic, one
+  // VALU address per LDS read) on 4-8 MFMAs of 32 cycles - with four waves per SIMD the instruction issue, not the matrix pipe, set
+  // the pace (PMC: SQ_ACTIVE_INST_ANY 0.35 of the wave cycles). Lean form: unrolled by 6 = ring slot (mod 3) x register set (mod 2),
+  // so every LDS read is `base + immediate` and every DMA destination `base + immediate`; the counted wait is an immediate; the last
+  // three slabs still "issue" their pieces, with out-of-range offsets (zero fill, no memory traffic), so every iteration is the
+  // same straight-line code; 1x1 kernels pass the slab's K offset as the scalar offset of the load (no VALU at all per piece).
+  constexpr bool LEAN = (BM % 64 == 0) && (BN % 64 == 0);
+  // 64x64 wave tiles keep ONE fragment set (read after the MFMAs of the slab before, exposed LDS latency covered by the other waves):
+  // 32 VGPRs fewer = three workgroups per CU instead of two, i.e. 144 KB instead of 96 KB of the 160 KB LDS holding DMA data in flight
+  constexpr bool DBUF = (TM * TN < 4);
+  if constexpr (LEAN) {
+    constexpr int NPW = AI + BI;                          // pieces per wave and slab, the same for every wave
+    const unsigned bA0 = lds_base + (unsigned)(aoff + fo0), bA1 = lds_base + (unsigned)(aoff + fo1);
+    const unsigned bB0 = lds_base + (unsigned)(boff + fo0), bB1 = lds_base + (unsigned)(boff + fo1);
+    char* const dA = smem_h + 1024 * wave;                // + SLOT * SLAB + 4096 * j
+    char* const dB = smem_h + BM * 64 + 1024 * wave;
+    unsigned aoffs_l[AI];
+#pragma unroll
+    for (int j = 0; j < AI; ++j) aoffs_l[j] = (ONE_TAP && !(amask[j] & 1ull)) ? 0xFFFFFFF0u : aoffs[j];   // 1x1: row validity folded in
+    int g3 = 0;                                           // slab being issued
+    int l_tb = 0, l_tap = 0; bool l_cok = true;
+    auto lean_begin = [&]() {                             // spatial kernels: tap state of slab g3 (as issue_begin)
+      if constexpr (!ONE_TAP) {
+        const int tb0 = ((kh0 * p.dh * p.W + kw0 * p.dw) * p.ldx + ci0) * 2;
+        int cil = ci0;
+        l_tb = tb0; l_tap = tap0;
+        if (UNITS == 2) {
+          const int tb1 = ((kh1 * p.dh * p.W + kw1 * p.dw) * p.ldx + ci1) * 2;
+          l_tb = upar ? tb1 : tb0; l_tap = upar ? tap1 : tap0; cil = upar ? ci1 : ci0;
+        }
+        l_cok = (cil + cofs) < p.Cin;
+      }
+    };
+    auto lean_end = [&]() {
+      if constexpr (!ONE_TAP) {
+        advance(tap0, kh0, kw0, ci0);
+        if (UNITS == 2) advance(tap1, kh1, kw1, ci1);
+      }
+      ++g3;
+    };
+#define FL_PIECE(SLOT, Q)                                                                                               \
+    {                                                                                                                   \
+      const bool live_ = g3 < nsub;                                                                                     \
+      if constexpr ((Q) < AI) {                                                                                         \
+        if constexpr (ONE_TAP) {                                                                                        \
+          const unsigned off_ = live_ ? aoffs_l[(Q) < AI ? (Q) : 0] : 0xFFFFFFF0u;                                      \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 4096 * (Q)), 16, (int)off_, g3 * 64, 0, 0);   \
+        } else {                                                                                                        \
+          const bool ok_ = ((amask[(Q) < AI ? (Q) : 0] >> l_tap) & 1ull) && l_cok && live_;                              \
+          const unsigned off_ = ok_ ? aoffs[(Q) < AI ? (Q) : 0] + (unsigned)l_tb : 0xFFFFFFF0u;                          \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 4096 * (Q)), 16, (int)off_, 0, 0, 0);         \
+        }                                                                                                               \
+      } else {                                                                                                          \
+        const unsigned off_ = live_ ? boffs[(Q) >= AI ? (Q) - AI : 0] : 0xFFFFFFF0u;                                    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(dB + (SLOT) * SLAB + 4096 * ((Q) - AI)), 16, (int)off_, g3 * 64, 0, 0); \
+      }                                                                                                                 \
+    }
+#define FL_READ1(DST, BASE, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "i"(IMM));
+#define FL_READ_FRAGS(SET, SLOT)                                                                                        \
+    {                                                                                                                   \
+      FL_READ1(fa[SET][0], bA0, (SLOT) * SLAB) FL_READ1(fa[SET][1], bA1, (SLOT) * SLAB)                                 \
+      if constexpr (TM > 1) { FL_READ1(fa[SET][2], bA0, (SLOT) * SLAB + 2048) FL_READ1(fa[SET][3], bA1, (SLOT) * SLAB + 2048) } \
+      FL_READ1(fb[SET][0], bB0, (SLOT) * SLAB) FL_READ1(fb[SET][1], bB1, (SLOT) * SLAB)                                 \
+      if constexpr (TN > 1) { FL_READ1(fb[SET][2], bB0, (SLOT) * SLAB + 2048) FL_READ1(fb[SET][3], bB1, (SLOT) * SLAB + 2048) } \
+    }
+#define FL_MFMA(SET, Q)                                                                                                 \
+    {                                                                                                                   \
+      constexpr int hh_ = (Q) / (TM * TN), i_ = ((Q) / TN) % TM, j_ = (Q) % TN;                                         \
+      H8 a_, b_;                                                                                                        \
+      a_.f = fa[SET][2 * i_ + hh_]; b_.f = fb[SET][2 * j_ + hh_];                                                       \
+      acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i_][j_], 0, 0, 0);                          \
+    }
+#define FL_PIECE_AT(SLOT, N, Q)                                                                                          \
+    if constexpr ((N) < NPW && (((N) + 1) * (2 * TM * TN) / (NPW + 1) - 1 < 0 ? 0 : ((N) + 1) * (2 * TM * TN) / (NPW + 1) - 1) == (Q)) { \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+      FL_PIECE(SLOT, N)                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }
+#define FL_STEP_Q(CUR, SLOTI, Q)                                                                                         \
+    if constexpr ((Q) < 2 * TM * TN) {                                                                                   \
+      FL_MFMA(CUR, Q)                                                                                                    \
+      FL_PIECE_AT(SLOTI, 0, Q) FL_PIECE_AT(SLOTI, 1, Q) FL_PIECE_AT(SLOTI, 2, Q) FL_PIECE_AT(SLOTI, 3, Q) FL_PIECE_AT(SLOTI, 4, Q) FL_PIECE_AT(SLOTI, 5, Q) \
+    }
+    // slab g (fragments in set CUR): wait for this wave's pieces of slab g+1, publish it, read its fragments into the other set,
+    // MFMAs of slab g with the pieces of slab g+3 (ring slot SLOTI = g % 3) between them
+#define FL_SLAB(CUR_, NXT_, SLOTR, SLOTI)                                                                                \
+    {                                                                                                                    \
+      constexpr int CUR = DBUF ? (CUR_) : 0, NXT = DBUF ? (NXT_) : 0;                                                    \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPW) : "memory");                                                         \
+      __builtin_amdgcn_s_barrier();                                                                                      \
+      lean_begin();                                                                                                      \
+      if constexpr (DBUF) { FL_READ_FRAGS(NXT, SLOTR) }                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+      FL_STEP_Q(CUR, SLOTI, 0) FL_STEP_Q(CUR, SLOTI, 1) FL_STEP_Q(CUR, SLOTI, 2) FL_STEP_Q(CUR, SLOTI, 3)                \
+      FL_STEP_Q(CUR, SLOTI, 4) FL_STEP_Q(CUR, SLOTI, 5) FL_STEP_Q(CUR, SLOTI, 6) FL_STEP_Q(CUR, SLOTI, 7)                \
+      lean_end();                                                                                                        \
+      if constexpr (!DBUF) { __builtin_amdgcn_sched_barrier(0); FL_READ_FRAGS(NXT, SLOTR) }                              \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }
+    static_assert(NPW <= 6 && 2 * TM * TN <= 8, "lean loop: piece / MFMA slots");
+    // prologue: slabs 0, 1, 2 (slab 2 is a dummy when nsub == 2)
+#define FL_ISSUE_ALL(SLOT) { lean_begin(); FL_PIECE_ALL(SLOT) lean_end(); }
+#define FL_PIECE_N(SLOT, N) if constexpr ((N) < NPW) FL_PIECE(SLOT, N)
+#define FL_PIECE_ALL(SLOT) FL_PIECE_N(SLOT, 0) FL_PIECE_N(SLOT, 1) FL_PIECE_N(SLOT, 2) FL_PIECE_N(SLOT, 3) FL_PIECE_N(SLOT, 4) FL_PIECE_N(SLOT, 5)
+    FL_ISSUE_ALL(0) FL_ISSUE_ALL(1) FL_ISSUE_ALL(2)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    FL_READ_FRAGS(0, 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < nsub; g += 6) {      // nsub is even
+      FL_SLAB(0, 1, 1, 0)
+      FL_SLAB(1, 0, 2, 1)
+      if (g + 2 < nsub) {
+        FL_SLAB(0, 1, 0, 2)
+        FL_SLAB(1, 0, 1, 0)
+      }
+      if (g + 4 < nsub) {
+        FL_SLAB(0, 1, 2, 1)
+        FL_SLAB(1, 0, 0, 2)
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy pieces of the tail have landed before the epilogue reuses the ring
+#undef FL_SLAB
+#undef FL_STEP_Q
+#undef FL_PIECE_AT
+#undef FL_MFMA
+#undef FL_READ_FRAGS
+#undef FL_READ1
+#undef FL_PIECE
+#undef FL_ISSUE_ALL
+#undef FL_PIECE_N
+#undef FL_PIECE_ALL
+  } else {
   issue_step(0);
   if (nsteps > 1) issue_step(1);
   if (nsteps > 2) issue_step(2);
@@ -252,8 +411,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_bf16_kernel(
     FH_SLAB(0, 1, g)
     FH_SLAB(1, 0, g + 1)     // nsub is even (Kp % 64 == 0)
   }
+  }
 #undef FH_SLAB
-#undef FH_MFMA_BURST
+#undef FH_MFMA_BURST_ISSUE
 #undef FH_READ_FRAGS
   __syncthreads();   // all fragment reads retired before the epilogue reuses the ring as staging
 
@@ -340,7 +500,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_bf16_kernel(
           float x = v[e] * sc[e] + sf[e];
           if (p.res && !p.res_after_act) x += rf[e];
           if constexpr (MODE == 2) x = x > 0.f ? x : x * sl[e];
-          else x = fe_apply_act(x, p.act);
+          else x = fe_apply_act_fast(x, p.act);
           if (p.res && p.res_after_act) x += rf[e];
           if (p.gate) x *= p.gate_c1 ? gs[it] : gf[e];
           if (!cfull && colb + e >= p.Cout) x = 0.f;
@@ -381,37 +541,39 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_bf16_kernel(
   }
 }
 
-template <int WGM, int WGN, int TM, int TN, int UNITS, int KB, int MODE = 0>
+template <int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
 static void launch_bf16_variant(const ConvParamsH& p, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
-  constexpr size_t main_lds = (size_t)3 * KB * (BM + BN) * 64;
+  constexpr size_t main_lds = (size_t)3 * (BM + BN) * 64;
   constexpr size_t epi_lds = (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
-  auto kern = conv_bf16_kernel<WGM, WGN, TM, TN, UNITS, KB, MODE>;
+  auto kern = conv_bf16_kernel<WGM, WGN, TM, TN, UNITS, MODE, ONE_TAP>;
   static std::atomic<uint64_t> lds_set{0};
   ensure_dynamic_lds((const void*)kern, lds, lds_set);
   hipLaunchKernelGGL(kern, dim3(mtiles * ntiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, ntiles);
   FE_HIP(hipGetLastError());
 }
 
-template <int UNITS, int KB>
-static void launch_bf16_tile(const ConvParamsH& p, int tile, hipStream_t s) {
-  if (p.act == ACT_PRELU) {
-    FE_CHECK(p.slope, "conv_bf16: PReLU without slopes");
-    switch (tile) {
-      case 4: launch_bf16_variant<2, 2, 1, 1, UNITS, KB, 2>(p, s); break;
-      case 7: launch_bf16_variant<2, 2, 2, 1, UNITS, KB, 2>(p, s); break;
-      default: launch_bf16_variant<2, 2, 2, 2, UNITS, KB, 2>(p, s); break;
+template <int UNITS>
+static void launch_bf16_tile(const ConvParamsH& p, int tile, bool one_tap, hipStream_t s) {
+  FE_CHECK(p.act != ACT_PRELU, "conv_bf16: PReLU epilogue is not instantiated (no bf16 model uses it)");
+  if constexpr (UNITS == 1) {
+    if (one_tap) {      // 1x1 kernels with Cin % 64 == 0: K offset as the scalar offset of the loads, no tap masks
+      switch (tile) {
+        case 1: launch_bf16_variant<2, 2, 2, 2, 1, 0, true>(p, s); return;   // 128x128
+        case 7: launch_bf16_variant<2, 2, 2, 1, 1, 0, true>(p, s); return;   // 128x64
+        case 4: launch_bf16_variant<2, 2, 1, 1, 1, 0, true>(p, s); return;   // 64x64
+        default: break;
+      }
     }
-    return;
   }
   switch (tile) {
-    case 1: launch_bf16_variant<2, 2, 2, 2, UNITS, KB>(p, s); break;   // 128x128
-    case 7: launch_bf16_variant<2, 2, 2, 1, UNITS, KB>(p, s); break;   // 128x64
-    case 4: launch_bf16_variant<2, 2, 1, 1, UNITS, KB>(p, s); break;   // 64x64
-    case 3: launch_bf16_variant<4, 1, 2, 1, UNITS, KB>(p, s); break;   // 256x32
-    case 5: launch_bf16_variant<4, 1, 1, 1, UNITS, KB>(p, s); break;   // 128x32
+    case 1: launch_bf16_variant<2, 2, 2, 2, UNITS>(p, s); break;   // 128x128
+    case 7: launch_bf16_variant<2, 2, 2, 1, UNITS>(p, s); break;   // 128x64
+    case 4: launch_bf16_variant<2, 2, 1, 1, UNITS>(p, s); break;   // 64x64
+    case 3: launch_bf16_variant<4, 1, 2, 1, UNITS>(p, s); break;   // 256x32
+    case 5: launch_bf16_variant<4, 1, 1, 1, UNITS>(p, s); break;   // 128x32
     default: FE_CHECK(false, "conv_bf16: unknown tile %d", tile);
   }
 }
@@ -446,8 +608,12 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
   // tile choice: same wave-quantisation model as the fp32 kernel (launch_conv in kernels_conv.hip)
   int tile = p.variant;
   if (tile == 0) {
+    // Measured (tools/perf_clip.py / perf_topiq.py with FE_BF16_TILE): the 128x128 tile (three workgroups per CU) wins once the K loop
+    // dominates the launch (K >= 2048: 713 vs 545 TFLOP/s on K = 4096); below that the 128x64 tile's four workgroups per CU hide
+    // prologue and epilogue better (K = 1024: 560 vs 459); K <= 256 is bound by the output / residual streams either way.
     struct Cand { int tile, bm, bn; double eff; };
-    static const Cand wide[3] = {{7, 128, 64, 1.00}, {1, 128, 128, 0.88}, {4, 64, 64, 0.86}};   // measured: tools/perf_clip.py / perf_topiq.py with FE_BF16_TILE
+    const bool longk = p.K >= 2048;
+    const Cand wide[3] = {{7, 128, 64, longk ? 0.78 : 1.00}, {1, 128, 128, longk ? 1.00 : 0.80}, {4, 64, 64, longk ? 0.60 : 0.86}};
     static const Cand narrow[2] = {{7, 128, 64, 1.00}, {4, 64, 64, 0.90}};
     static const Cand slim[2] = {{3, 256, 32, 1.00}, {5, 128, 32, 0.92}};
     const Cand* cs = p.Cout > 64 ? wide : (p.Cout > 32 ? narrow : slim);
@@ -455,7 +621,7 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
     double best = 1e300;
     for (int i = 0; i < nc; ++i) {
       // short K: the launch is bound by its output / residual streams, not by the matrix pipes - the 128x64 tile keeps four
-      // workgroups per CU in flight (120 VGPRs, 36 KB of LDS) where the 128x128 tile fits two
+      // workgroups per CU in flight (128 VGPRs, 36 KB of LDS) where the 128x128 tile fits three
       if (p.Cout > 64 && p.K <= 256 && cs[i].tile == 1) continue;
       const long long wgs = (long long)((p.M + cs[i].bm - 1) / cs[i].bm) * ((p.Cout + cs[i].bn - 1) / cs[i].bn) * p.batch;
       const double cost = (double)((wgs + 255) / 256) * cs[i].bm * cs[i].bn / cs[i].eff;
@@ -466,8 +632,9 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
   // measured 733 vs 1028 images/s on TOPIQ - occupancy beats barrier count here
   static const int force_tile = getenv("FE_BF16_TILE") ? atoi(getenv("FE_BF16_TILE")) : 0;   // A/B hook
   if (force_tile && p.variant == 0 && p.Cout > 32) tile = force_tile;
-  if (p.cb == 16) launch_bf16_tile<2, 1>(p, tile, s);
-  else launch_bf16_tile<1, 1>(p, tile, s);
+  const bool one_tap = ntaps == 1 && p.Cin % 64 == 0 && p.Kp == p.Cin;
+  if (p.cb == 16) launch_bf16_tile<2>(p, tile, false, s);
+  else launch_bf16_tile<1>(p, tile, one_tap, s);
 }
 
 }  // namespace fe

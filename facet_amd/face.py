@@ -12,7 +12,7 @@ What runs where:
       post-processing (gray / Laplacian variance on small ROIs, EAR, aggregation) and JPEG thumbnails.
 The three networks are the reference's own files: <root>/models/buffalo_l/{det_10g,2d106det,w600k_r50}.onnx (insightface's
 layout, root='~/.insightface' at face.py:34), parsed by the engine's ONNX runtime; `models=` passes bytes directly (tests use
-facet_amd.synthetic_onnx). insightface internals follow the published package [DEP-KNOWLEDGE]; cv2 is not importable here, so
+standins.synthetic_onnx). insightface internals follow the published package [DEP-KNOWLEDGE]; cv2 is not importable here, so
 gray/Laplacian are restated in numpy and thumbnails are encoded with Pillow (not bit-identical to cv2.imencode).
 """
 import io
@@ -293,24 +293,25 @@ class FaceAnalyzer:
             print(f"InsightFace not available: {e}")
 
     def _crop_face_thumbnail(self, img_cv, bbox, padding=0.3):
+        """JPEG bytes of the face box grown by `padding` of its size on every side (clipped to the image) and scaled so its longer edge
+        is `thumbnail_size` - the arithmetic of the reference's helper (analyzers/face.py:52-82: int() truncation of the box, of the
+        padding and of the scaled size), with Pillow doing the resampling and encoding (cv2 is not available: pixels are close to,
+        not identical with, the reference's INTER_AREA + cv2.imencode bytes)."""
         try:
             from PIL import Image
-            x1, y1, x2, y2 = [int(v) for v in bbox]
-            h, w = img_cv.shape[:2]
-            face_w, face_h = x2 - x1, y2 - y1
-            pad_x, pad_y = int(face_w * padding), int(face_h * padding)
-            x1, y1 = max(0, x1 - pad_x), max(0, y1 - pad_y)
-            x2, y2 = min(w, x2 + pad_x), min(h, y2 + pad_y)
-            face_crop = img_cv[y1:y2, x1:x2]
-            if face_crop.size == 0:
+            left, top, right, bottom = (int(v) for v in bbox)
+            grow_x, grow_y = int((right - left) * padding), int((bottom - top) * padding)
+            rows = slice(max(0, top - grow_y), min(img_cv.shape[0], bottom + grow_y))
+            cols = slice(max(0, left - grow_x), min(img_cv.shape[1], right + grow_x))
+            crop = img_cv[rows, cols]
+            if crop.size == 0:
                 return None
-            crop_h, crop_w = face_crop.shape[:2]
-            scale = self.thumbnail_size / max(crop_h, crop_w)
-            new_w, new_h = int(crop_w * scale), int(crop_h * scale)
-            im = Image.fromarray(np.ascontiguousarray(face_crop[:, :, ::-1])).resize((new_w, new_h), Image.BOX)
-            buf = io.BytesIO()
-            im.save(buf, format='JPEG', quality=int(self.thumbnail_quality))
-            return buf.getvalue()
+            factor = self.thumbnail_size / max(crop.shape[0], crop.shape[1])
+            size = (int(crop.shape[1] * factor), int(crop.shape[0] * factor))            # PIL takes (width, height)
+            thumb = Image.fromarray(np.ascontiguousarray(crop[:, :, ::-1])).resize(size, Image.BOX)
+            out = io.BytesIO()
+            thumb.save(out, format='JPEG', quality=int(self.thumbnail_quality))
+            return out.getvalue()
         except Exception:
             return None
 

@@ -1,7 +1,7 @@
 """Minimal ONNX (protobuf wire format) writer: just enough of onnx.ModelProto to emit the graphs the engine's runtime reads.
 
 There is no `onnx` package in this environment, and the reference's face models (buffalo_l: det_10g.onnx, 2d106det.onnx,
-w600k_r50.onnx, fetched by insightface at analyzers/face.py:30-38) are not on disk; `facet_amd.synthetic_onnx` uses this
+w600k_r50.onnx, fetched by insightface at analyzers/face.py:30-38) are not on disk; `standins.synthetic_onnx` uses this
 writer to build seeded stand-ins of the same architectures for tests and benchmarks. Field numbers follow the public
 onnx.proto3 schema; tensors are written as little-endian raw_data, like torch.onnx.export does.
 """
@@ -106,7 +106,7 @@ def value_info(name, dims, elem_type=FLOAT):
     return _str(1, name) + _ld(2, _ld(1, tensor_type))
 
 
-def model(nodes, initializers, inputs, outputs, opset=11, producer="facet_amd.onnx_writer", graph_name="g", encoding="raw",
+def model(nodes, initializers, inputs, outputs, opset=11, producer="standins.onnx_writer", graph_name="g", encoding="raw",
           list_initializers_as_inputs=False):
     """nodes: list of node() payloads; initializers: {name: ndarray}; inputs/outputs: [(name, dims)].
     list_initializers_as_inputs: IR < 4 files also declare every initializer as a graph input."""
@@ -176,5 +176,5 @@ class GraphBuilder:
             ins.append(self.const((self.rng.standard_normal(cout) * 0.05).astype(np.float32), "b"))
         return self.op("Gemm", ins, alpha=1.0, beta=1.0, transB=int(trans_b))
 
-    def build(self, inputs, outputs, producer="facet_amd.onnx_writer", **kw):
+    def build(self, inputs, outputs, producer="standins.onnx_writer", **kw):
         return model(self.nodes, self.init, inputs, outputs, opset=self.opset, producer=producer, **kw)

@@ -3,7 +3,7 @@
 The real files (det_10g.onnx = SCRFD-10GF with keypoints, 2d106det.onnx = 106-point landmark regressor,
 w600k_r50.onnx = ArcFace IResNet-50) are downloaded by insightface at run time and are not available offline, so tests
 and benchmarks build graphs of the same public architectures [DEP-KNOWLEDGE: insightface model zoo / arcface_torch
-iresnet.py / mmdet SCRFD configs] with seeded weights, written as genuine .onnx bytes by `facet_amd.onnx_writer`. The
+iresnet.py / mmdet SCRFD configs] with seeded weights, written as genuine .onnx bytes by `standins.onnx_writer`. The
 engine treats them exactly like the real files; with real files on disk, pass those bytes instead.
 
 Every builder returns (onnx_bytes, info) where info carries the input size, the MACs per image and layout facts.

@@ -56,7 +56,7 @@ def test_plain_c_program_links_and_runs(tmp_path):
     without a GPU it must still start, parse a model with the host-only entry point and report the missing device cleanly."""
     import shutil
     import subprocess
-    from facet_amd import synthetic_onnx as S
+    from standins import synthetic_onnx as S
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")

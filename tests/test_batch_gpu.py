@@ -5,7 +5,7 @@ import types
 import numpy as np
 import pytest
 
-from facet_amd import synthetic_onnx as S
+from standins import synthetic_onnx as S
 from facet_amd._lib import FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_AESTHETIC, FE_MODEL_SAMP, FE_MODEL_U2NETP
 from facet_amd.batch import BatchScorer
 from facet_amd.face import FaceAnalyzer

@@ -94,7 +94,7 @@ def test_topiq_long_edge_cap_matches_reference_preprocessing(engine):
 
 # ---- face / statistics entry points: empty results, degenerate shapes, misuse ------------------------------------------------
 def test_face_analyze_without_detections_and_without_models(engine):
-    from facet_amd import synthetic_onnx as S
+    from standins import synthetic_onnx as S
     from facet_amd._lib import EngineError, FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC
     imgs = np.random.default_rng(0).integers(0, 256, (2, 96, 160, 3), dtype=np.uint8)
     for slot in (FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC):

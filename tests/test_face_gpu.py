@@ -7,7 +7,7 @@ algorithms and both sides run the same seeded stand-in .onnx graphs (facet_amd/s
 import numpy as np
 import pytest
 
-from facet_amd import synthetic_onnx as S
+from standins import synthetic_onnx as S
 from facet_amd._lib import FE_GRAPH_FACE_REC
 from facet_amd.face import ARCFACE_DST, FaceAnalyzer, FaceEngine, similarity_from_5pts
 from oracle import face_ref

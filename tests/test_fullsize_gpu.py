@@ -61,7 +61,7 @@ def test_topiq_fullsize_vs_oracle(big_engine):
 
 
 def test_face_detect_fullsize_vs_oracle(big_engine):
-    from facet_amd import synthetic_onnx as S
+    from standins import synthetic_onnx as S
     from facet_amd.face import FaceEngine
     from oracle import face_ref
     det = S.scrfd_like(seed=12, size=640)[0]

@@ -7,8 +7,8 @@ Tolerance: 1e-3 of the output's max magnitude (fp32 both sides, different summat
 import numpy as np
 import pytest
 
-from facet_amd import onnx_writer as W
-from facet_amd import synthetic_onnx as S
+from standins import onnx_writer as W
+from standins import synthetic_onnx as S
 from oracle import onnx_ref
 
 pytestmark = pytest.mark.gpu

@@ -3,8 +3,8 @@ reader must agree on the same bytes; malformed files are rejected with a message
 import numpy as np
 import pytest
 
-from facet_amd import onnx_writer as W
-from facet_amd import synthetic_onnx as S
+from standins import onnx_writer as W
+from standins import synthetic_onnx as S
 from facet_amd._lib import EngineError, onnx_probe
 from oracle import onnx_ref
 

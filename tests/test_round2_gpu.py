@@ -124,7 +124,8 @@ import numpy as np
 sys.path.insert(0, os.environ["FACET_ROOT"])
 os.environ["FACET_AMD_SYNTHETIC"] = "1"
 import torch, torch.distributed as dist
-from facet_amd import Engine, synthetic_onnx as SO
+from facet_amd import Engine
+from standins import synthetic_onnx as SO
 from facet_amd._lib import (FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_AESTHETIC, FE_MODEL_SAMP, FE_MODEL_U2NETP, FE_GRAPH_FACE_DET,
                             FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC)
 from facet_amd.weights import synthetic_state_dict, synthetic_images

@@ -3,7 +3,7 @@
 import sys
 import numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from facet_amd import synthetic_onnx as S, onnx_writer as W
+from standins import synthetic_onnx as S, onnx_writer as W
 from facet_amd._lib import Engine
 from oracle import onnx_ref
 
@@ -17,7 +17,7 @@ elif which == "lmk":
     x = np.random.default_rng(4).uniform(0, 255, (2, 3, 192, 192)).astype(np.float32)
 m = onnx_ref.parse(g_data)
 # rebuild the same bytes with all node outputs exported
-import facet_amd.onnx_writer as ow
+import standins.onnx_writer as ow
 nodes = []
 for n in m["nodes"]:
     nodes.append(ow.node(n["op"], n["in"], n["out"], n["name"], **{k: (v if not isinstance(v, np.ndarray) else v) for k, v in n["attr"].items()}))

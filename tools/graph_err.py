@@ -2,7 +2,7 @@
 import sys
 import numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from facet_amd import synthetic_onnx as S
+from standins import synthetic_onnx as S
 from facet_amd._lib import Engine
 from oracle import onnx_ref
 e = Engine(0, arena_bytes=6 << 30)

@@ -3,7 +3,8 @@ host-side assembly of the per-image dicts. usage: perf_batch_step.py [n] [hw]"""
 import cProfile, io, json, os, pstats, sys, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from facet_amd import Engine, synthetic_onnx as S
+from facet_amd import Engine
+from standins import synthetic_onnx as S
 from facet_amd._lib import FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_AESTHETIC, FE_MODEL_SAMP, FE_MODEL_U2NETP
 from facet_amd.aggregate import AggregatePolicy
 from facet_amd.batch import BatchScorer

@@ -3,7 +3,7 @@ and landmark graphs on batches of crops. Synthetic stand-in graphs (facet_amd/sy
 import sys, time
 import numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from facet_amd import synthetic_onnx as S
+from standins import synthetic_onnx as S
 from facet_amd._lib import Engine, FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC
 
 e = Engine(0, arena_bytes=48 << 30)
