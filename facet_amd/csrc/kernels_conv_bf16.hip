@@ -421,132 +421,264 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
 #undef FH_READ_FRAGS
   __syncthreads();   // all fragment reads retired before the epilogue reuses the ring as staging
 
-  // ---- epilogue: transpose through a wave-private LDS region; each lane then owns 8 consecutive channels of a row -----------
-  // Code size matters here: the activation chain (erf, exp, log1p) inlined into a fully unrolled epilogue came to ~37k instructions
-  // per kernel, more than the instruction cache holds, and cost the 128x128 tile ~25 us per workgroup. So only the accumulator ->
-  // LDS writes are unrolled (register indices); the read-back / scale / residual / activation / gate / store part is ONE rolled loop
-  // over the lane's rows with the next row's residual and gate requested an iteration ahead; 16-byte accesses when legal
-  // (p.vec_epi), per-element ones otherwise.
-  float* smem = reinterpret_cast<float*>(smem_h);
-  constexpr int WC = TN * 32, ES = WC + 4, LPR = WC / 8, RPI = 64 / LPR, NIT = 32 / RPI;
-  float* E = smem + wave * 32 * ES;
-  const int lr = lane / LPR, lc = (lane % LPR) * 8;
-  const int colb = n0 + wn * WC + lc;
-  const bool vec = p.vec_epi != 0;
-  const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
-  const bool cok = colb < climit;                        // the lane has at least one column to store
-  const bool cfull = colb + 8 <= p.Cout;
-  float sc[8], sf[8], sl[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const bool cv = colb + e < p.Cout;
-    sc[e] = (cv && p.scale) ? p.scale[colb + e] : 1.f;
-    sf[e] = (cv && p.shift) ? p.shift[colb + e] : 0.f;
-    sl[e] = (MODE == 2 && cv) ? p.slope[colb + e] : 0.f;
-  }
-  const int act = p.act;
-  // 8 channels of one row of a bf16 tensor as one packed 16-byte value: one vector load, or per-element loads (zeros past Cout)
-  auto load8 = [&](const bf16* base, size_t row_off) -> uint4 {
-    if (vec && cfull) return *reinterpret_cast<const uint4*>(base + row_off + colb);
-    const unsigned short* b16 = reinterpret_cast<const unsigned short*>(base) + row_off + colb;
-    unsigned w[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) w[e] = (colb + e < p.Cout) ? (unsigned)b16[e] : 0u;
-    return make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16));
-  };
-  auto row_of = [&](int i, int it) { return m0 + wm * TM * 32 + i * 32 + lr + it * RPI; };
-  auto fetch_res = [&](int m) -> uint4 {
-    const int mc = m < p.M ? m : p.M - 1;
-    return p.res ? load8(p.res, (size_t)mc * p.ldr) : make_uint4(0, 0, 0, 0);
-  };
-  auto fetch_gate = [&](int m) -> uint4 {      // gate_c1: the single channel's value in .x (as float bits)
-    const int mc = m < p.M ? m : p.M - 1;
-    if (!p.gate) return make_uint4(0, 0, 0, 0);
-    if (p.gate_c1) return make_uint4(__float_as_uint((float)p.gate[(size_t)mc * p.ldg]), 0, 0, 0);
-    return load8(p.gate, (size_t)mc * p.ldg);
-  };
-  // one row of the lane: E -> scale / shift / residual / activation / gate -> store
-  auto finish_row = [&](int m, int erow, const uint4 ru, const uint4 gu) {
-    const float4 v0 = *reinterpret_cast<const float4*>(&E[erow * ES + lc]);
-    const float4 v1 = *reinterpret_cast<const float4*>(&E[erow * ES + lc + 4]);
-    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    float rf[8], gf[8];
-    if (p.res) h_unpack8(ru, rf);
-    if (p.gate && !p.gate_c1) h_unpack8(gu, gf);
-    const float gs = __uint_as_float(gu.x);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float x = v[e] * sc[e] + sf[e];
-      if (p.res && !p.res_after_act) x += rf[e];
-      v[e] = x;
-    }
-    // one activation branch per row (block-uniform), not per element
-    if constexpr (MODE == 2) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
-    } else if (act == ACT_RELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-    } else if (act == ACT_GELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + fe_erf_fast(v[e] * 0.70710678118654752440f));
-    } else if (act == ACT_SIGMOID) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = __frcp_rn(1.f + __expf(-v[e]));
-    } else if (act == ACT_SOFTPLUS) {
-#pragma unroll 1
-      for (int e = 0; e < 8; ++e) v[e] = v[e] > 20.f ? v[e] : log1pf(expf(v[e]));
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float x = v[e];
-      if (p.res && p.res_after_act) x += rf[e];
-      if (p.gate) x *= p.gate_c1 ? gs : gf[e];
-      if (colb + e >= p.Cout) x = 0.f;                 // pad_store: the ragged tail of the last group is written as zeros
-      v[e] = x;
-    }
-    if (cok && m < p.M) {
-      bf16* yp = p.y + (size_t)m * p.ldy + colb;
-      if (vec) {
-        H8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o.b[e] = (bf16)v[e];
-        *reinterpret_cast<uint4*>(yp) = o.u;
-      } else {
-#pragma unroll
+  // Two epilogue forms (as in kernels_conv_dma.hip). Narrow wave tiles (TN = 1: the tiles of the HBM-bound short-K layers) keep the
+  // fully unrolled row code with every residual row requested up front (K = 64 -> 256 expand: 4.2 vs 3.8 TB/s against the rolled
+  // form: hipcc drains the outstanding loads at the scalar branches the rolled form has per row). Wide wave tiles take the compact
+  // rolled form.
+  if constexpr (TN == 1) {
+  // ---- epilogue: transpose through a wave-private LDS region, 8 bf16 (16 B) per lane and store ------------------
+    float* smem = reinterpret_cast<float*>(smem_h);
+    if (p.vec_epi) {
+      constexpr int WC = TN * 32, ES = WC + 4, LPR = WC / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+      float* E = smem + wave * 32 * ES;
+      const int lr = lane / LPR, lc = (lane % LPR) * 8;
+      const int colb = n0 + wn * WC + lc;
+      const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
+      const bool cok = colb < climit;
+      const int colc = (colb + 8 <= p.Cout) ? colb : 0;     // per-channel vectors are only read for fully valid groups
+      const bool cfull = colb + 8 <= p.Cout;
+      float sc[8], sf[8];
+  #pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sf[e] = 0.f; }
+      if (p.scale && cfull) {
+        const float4 a = *reinterpret_cast<const float4*>(p.scale + colc), b = *reinterpret_cast<const float4*>(p.scale + colc + 4);
+        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+      }
+      if (p.shift && cfull) {
+        const float4 a = *reinterpret_cast<const float4*>(p.shift + colc), b = *reinterpret_cast<const float4*>(p.shift + colc + 4);
+        sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+      }
+      if (!cfull && cok) {   // ragged last group (pad_store): scalar reads of what exists
+  #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (colb + e < p.Cout) yp[e] = (bf16)v[e];
+          if (colb + e < p.Cout) { if (p.scale) sc[e] = p.scale[colb + e]; if (p.shift) sf[e] = p.shift[colb + e]; }
+      }
+      float sl[8];
+      if constexpr (MODE == 2) {
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) sl[e] = (colb + e < p.Cout) ? p.slope[colb + e] : 0.f;
+      }
+      // residual rows of ALL the wave's 32-row slabs are requested up front (TM * NIT <= 8 x 16 B per lane): the short-K layers that
+      // carry a residual are bound by their HBM streams, and this doubles the bytes in flight during the LDS transposes
+      constexpr bool RES_AHEAD = (TM * NIT <= 8);
+      uint4 rall[RES_AHEAD ? TM * NIT : 1];
+      if constexpr (RES_AHEAD) {
+        if (p.res) {
+  #pragma unroll
+          for (int i = 0; i < TM; ++i)
+  #pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+              const int m = m0 + wm * TM * 32 + i * 32 + lr + it * RPI;
+              const int mc = m < p.M ? m : p.M - 1;
+              rall[i * NIT + it] = *reinterpret_cast<const uint4*>(p.res + (size_t)mc * p.ldr + colc);
+            }
+        }
+      }
+  #pragma unroll
+      for (int i = 0; i < TM; ++i) {
+  #pragma unroll
+        for (int j = 0; j < TN; ++j)
+  #pragma unroll
+          for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
+        const int mrow0 = m0 + wm * TM * 32 + i * 32 + lr;
+        uint4 rv[NIT];
+        float gs[NIT];
+        uint4 gv[NIT];
+  #pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int m = mrow0 + it * RPI;
+          const int mc = m < p.M ? m : p.M - 1;
+          if constexpr (RES_AHEAD) { if (p.res) rv[it] = rall[i * NIT + it]; }
+          else if (p.res) rv[it] = *reinterpret_cast<const uint4*>(p.res + (size_t)mc * p.ldr + colc);
+          if (p.gate) {
+            if (p.gate_c1) gs[it] = (float)p.gate[(size_t)mc * p.ldg];
+            else gv[it] = *reinterpret_cast<const uint4*>(p.gate + (size_t)mc * p.ldg + colc);
+          }
+        }
+  #pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int m = mrow0 + it * RPI;
+          const float4 v0 = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc]);
+          const float4 v1 = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc + 4]);
+          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          float rf[8], gf[8];
+          if (p.res) h_unpack8(rv[it], rf);
+          if (p.gate && !p.gate_c1) h_unpack8(gv[it], gf);
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e] * sc[e] + sf[e];
+            if (p.res && !p.res_after_act) x += rf[e];
+            if constexpr (MODE == 2) x = x > 0.f ? x : x * sl[e];
+            else x = fe_apply_act_fast(x, p.act);
+            if (p.res && p.res_after_act) x += rf[e];
+            if (p.gate) x *= p.gate_c1 ? gs[it] : gf[e];
+            if (!cfull && colb + e >= p.Cout) x = 0.f;
+            v[e] = x;
+          }
+          H8 o;
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) o.b[e] = (bf16)v[e];
+          if (cok && m < p.M) *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + colb) = o.u;
+        }
+      }
+      return;
+    }
+    // scalar epilogue (Cout or a stride not a multiple of 8): rare, small layers only
+  #pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + r;
+      const bool cok = col < p.Cout;
+      const float sc = (cok && p.scale) ? p.scale[col] : 1.f;
+      const float sf = (cok && p.shift) ? p.shift[col] : 0.f;
+  #pragma unroll
+      for (int i = 0; i < TM; ++i) {
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int m = m0 + row;
+          if (cok && m < p.M) {
+            float v = acc[i][j][e] * sc + sf;
+            if (p.res && !p.res_after_act) v += (float)p.res[(size_t)m * p.ldr + col];
+            if constexpr (MODE == 2) v = v > 0.f ? v : v * p.slope[col];
+            else v = fe_apply_act(v, p.act);
+            if (p.res && p.res_after_act) v += (float)p.res[(size_t)m * p.ldr + col];
+            if (p.gate) v *= (float)p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
+            p.y[(size_t)m * p.ldy + col] = (bf16)v;
+          }
+        }
       }
     }
-  };
-  // Narrow wave tiles (TN = 1: two rows per lane and 32-row slab; the tiles of the HBM-bound short-K layers) request the residual /
-  // gate rows of ALL their slabs before the first transpose - twice the bytes in flight; their row loop is short enough to unroll.
-  constexpr bool AHEAD = (TN == 1);
-  uint4 rall[AHEAD ? TM * NIT : 1], gall[AHEAD ? TM * NIT : 1];
-  if constexpr (AHEAD) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) { rall[i * NIT + it] = fetch_res(row_of(i, it)); gall[i * NIT + it] = fetch_gate(row_of(i, it)); }
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
+  
+    return;
+  } else {
+  // ---- epilogue: transpose through a wave-private LDS region; each lane then owns 8 consecutive channels of a row -----------
+    // Code size matters here: the activation chain (erf, exp, log1p) inlined into a fully unrolled epilogue came to ~37k instructions
+    // per kernel, more than the instruction cache holds, and cost the 128x128 tile ~25 us per workgroup. So only the accumulator ->
+    // LDS writes are unrolled (register indices); the read-back / scale / residual / activation / gate / store part is ONE rolled loop
+    // over the lane's rows with the next row's residual and gate requested an iteration ahead; 16-byte accesses when legal
+    // (p.vec_epi), per-element ones otherwise.
+    float* smem = reinterpret_cast<float*>(smem_h);
+    constexpr int WC = TN * 32, ES = WC + 4, LPR = WC / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+    float* E = smem + wave * 32 * ES;
+    const int lr = lane / LPR, lc = (lane % LPR) * 8;
+    const int colb = n0 + wn * WC + lc;
+    const bool vec = p.vec_epi != 0;
+    const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
+    const bool cok = colb < climit;                        // the lane has at least one column to store
+    const bool cfull = colb + 8 <= p.Cout;
+    float sc[8], sf[8], sl[8];
+  #pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool cv = colb + e < p.Cout;
+      sc[e] = (cv && p.scale) ? p.scale[colb + e] : 1.f;
+      sf[e] = (cv && p.shift) ? p.shift[colb + e] : 0.f;
+      sl[e] = (MODE == 2 && cv) ? p.slope[colb + e] : 0.f;
+    }
+    const int act = p.act;
+    // 8 channels of one row of a bf16 tensor as one packed 16-byte value: one vector load, or per-element loads (zeros past Cout)
+    auto load8 = [&](const bf16* base, size_t row_off) -> uint4 {
+      if (vec && cfull) return *reinterpret_cast<const uint4*>(base + row_off + colb);
+      const unsigned short* b16 = reinterpret_cast<const unsigned short*>(base) + row_off + colb;
+      unsigned w[8];
+  #pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] = (colb + e < p.Cout) ? (unsigned)b16[e] : 0u;
+      return make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16));
+    };
+    auto row_of = [&](int i, int it) { return m0 + wm * TM * 32 + i * 32 + lr + it * RPI; };
+    auto fetch_res = [&](int m) -> uint4 {
+      const int mc = m < p.M ? m : p.M - 1;
+      return p.res ? load8(p.res, (size_t)mc * p.ldr) : make_uint4(0, 0, 0, 0);
+    };
+    auto fetch_gate = [&](int m) -> uint4 {      // gate_c1: the single channel's value in .x (as float bits)
+      const int mc = m < p.M ? m : p.M - 1;
+      if (!p.gate) return make_uint4(0, 0, 0, 0);
+      if (p.gate_c1) return make_uint4(__float_as_uint((float)p.gate[(size_t)mc * p.ldg]), 0, 0, 0);
+      return load8(p.gate, (size_t)mc * p.ldg);
+    };
+    // one row of the lane: E -> scale / shift / residual / activation / gate -> store
+    auto finish_row = [&](int m, int erow, const uint4 ru, const uint4 gu) {
+      const float4 v0 = *reinterpret_cast<const float4*>(&E[erow * ES + lc]);
+      const float4 v1 = *reinterpret_cast<const float4*>(&E[erow * ES + lc + 4]);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      float rf[8], gf[8];
+      if (p.res) h_unpack8(ru, rf);
+      if (p.gate && !p.gate_c1) h_unpack8(gu, gf);
+      const float gs = __uint_as_float(gu.x);
+  #pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e] * sc[e] + sf[e];
+        if (p.res && !p.res_after_act) x += rf[e];
+        v[e] = x;
+      }
+      // one activation branch per row (block-uniform), not per element
+      if constexpr (MODE == 2) {
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
+      } else if (act == ACT_RELU) {
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      } else if (act == ACT_GELU) {
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + fe_erf_fast(v[e] * 0.70710678118654752440f));
+      } else if (act == ACT_SIGMOID) {
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = __frcp_rn(1.f + __expf(-v[e]));
+      } else if (act == ACT_SOFTPLUS) {
+  #pragma unroll 1
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 20.f ? v[e] : log1pf(expf(v[e]));
+      }
+  #pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e];
+        if (p.res && p.res_after_act) x += rf[e];
+        if (p.gate) x *= p.gate_c1 ? gs : gf[e];
+        if (colb + e >= p.Cout) x = 0.f;                 // pad_store: the ragged tail of the last group is written as zeros
+        v[e] = x;
+      }
+      if (cok && m < p.M) {
+        bf16* yp = p.y + (size_t)m * p.ldy + colb;
+        if (vec) {
+          H8 o;
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) o.b[e] = (bf16)v[e];
+          *reinterpret_cast<uint4*>(yp) = o.u;
+        } else {
+  #pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (colb + e < p.Cout) yp[e] = (bf16)v[e];
+        }
+      }
+    };
+    // Narrow wave tiles (TN = 1: two rows per lane and 32-row slab; the tiles of the HBM-bound short-K layers) request the residual /
+    // gate rows of ALL their slabs before the first transpose - twice the bytes in flight; their row loop is short enough to unroll.
+    constexpr bool AHEAD = (TN == 1);
+    uint4 rall[AHEAD ? TM * NIT : 1];      // the gate (one layer type of the TOPIQ head) is fetched per row, just in time
     if constexpr (AHEAD) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) finish_row(row_of(i, it), lr + it * RPI, rall[i * NIT + it], gall[i * NIT + it]);
-    } else {
-      uint4 rn = fetch_res(row_of(i, 0)), gn = fetch_gate(row_of(i, 0));
-#pragma unroll 1
-      for (int it = 0; it < NIT; ++it) {
-        const uint4 ru = rn, gu = gn;
-        if (it + 1 < NIT) { rn = fetch_res(row_of(i, it + 1)); gn = fetch_gate(row_of(i, it + 1)); }
-        finish_row(row_of(i, it), lr + it * RPI, ru, gu);
+  #pragma unroll
+      for (int i = 0; i < TM; ++i)
+  #pragma unroll
+        for (int it = 0; it < NIT; ++it) rall[i * NIT + it] = fetch_res(row_of(i, it));
+    }
+  #pragma unroll
+    for (int i = 0; i < TM; ++i) {
+  #pragma unroll
+      for (int j = 0; j < TN; ++j)
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
+      if constexpr (AHEAD) {
+  #pragma unroll
+        for (int it = 0; it < NIT; ++it) finish_row(row_of(i, it), lr + it * RPI, rall[i * NIT + it], fetch_gate(row_of(i, it)));
+      } else {
+        uint4 rn = fetch_res(row_of(i, 0)), gn = fetch_gate(row_of(i, 0));
+  #pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+          const uint4 ru = rn, gu = gn;
+          if (it + 1 < NIT) { rn = fetch_res(row_of(i, it + 1)); gn = fetch_gate(row_of(i, it + 1)); }
+          finish_row(row_of(i, it), lr + it * RPI, ru, gu);
+        }
       }
     }
+  
   }
 }
 

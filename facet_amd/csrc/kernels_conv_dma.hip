@@ -282,96 +282,221 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
 #undef FE_READ_FRAGS
   __syncthreads();   // all fragment reads retired before the epilogue reuses the slabs as staging
 
+  // Two epilogue forms. Narrow wave tiles (TN = 1: the tiles of the HBM-bound short-K layers) keep the fully unrolled, branch-free
+  // row code with every residual row requested up front - measured 64.6 vs 55.1 TFLOP/s on the K = 64 -> 256 expand against the
+  // rolled form (hipcc drains the outstanding loads at the scalar branches the rolled form has per row). Wide wave tiles take the
+  // compact rolled form: unrolled, their epilogue spilled 70 registers and ran to tens of thousands of instructions.
+  if constexpr (TN == 1) {
   // ---- epilogue (same as conv_igemm_kernel): transpose through a wave-private LDS region ------------------
-  if (p.vec_epi) {
+    if (p.vec_epi) {
+      constexpr int WC = TN * 32, ES = WC + 4, LPR = WC / 4, RPI = 64 / LPR, NIT = 32 / RPI;
+      float* E = smem + wave * 32 * ES;
+      const int lr = lane / LPR, lc = (lane % LPR) * 4;
+      const int colb = n0 + wn * WC + lc;
+      const bool cok = colb < p.Cout;
+      const int colc = cok ? colb : 0;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + colc);
+      if (p.shift) sf = *reinterpret_cast<const float4*>(p.shift + colc);
+      // Narrow wave tiles (TN = 1: the 128x64 / 256x32 / 64x64 blocks that carry the HBM-bound short-K layers) fetch the residual
+      // rows of ALL their 32-row slabs up front: TM * NIT <= 8 float4 per lane, twice the bytes in flight while the accumulators
+      // go through the LDS transpose. Wider tiles load per slab (their registers are taken by the accumulators).
+      constexpr bool RES_AHEAD = (TM * NIT <= 8);
+      float4 rall[RES_AHEAD ? TM * NIT : 1];
+      if constexpr (RES_AHEAD) {
+        if (p.res) {
+  #pragma unroll
+          for (int i = 0; i < TM; ++i)
+  #pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+              const int m = m0 + wm * TM * 32 + i * 32 + lr + it * RPI;
+              const int mc = m < p.M ? m : p.M - 1;
+              rall[i * NIT + it] = *reinterpret_cast<const float4*>(p.res + (size_t)mc * p.ldr + colc);
+            }
+        }
+      }
+  #pragma unroll
+      for (int i = 0; i < TM; ++i) {
+  #pragma unroll
+        for (int j = 0; j < TN; ++j)
+  #pragma unroll
+          for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
+        const int mrow0 = m0 + wm * TM * 32 + i * 32 + lr;
+        float4 rv[NIT], gv[NIT];
+  #pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int m = mrow0 + it * RPI;
+          const int mc = m < p.M ? m : p.M - 1;
+          if constexpr (RES_AHEAD) { if (p.res) rv[it] = rall[i * NIT + it]; }
+          else if (p.res) rv[it] = *reinterpret_cast<const float4*>(p.res + (size_t)mc * p.ldr + colc);
+          if (p.gate) {
+            if (p.gate_c1) { const float g = p.gate[(size_t)mc * p.ldg]; gv[it] = make_float4(g, g, g, g); }
+            else gv[it] = *reinterpret_cast<const float4*>(p.gate + (size_t)mc * p.ldg + colc);
+          }
+        }
+  #pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int m = mrow0 + it * RPI;
+          float4 v = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc]);
+          v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+          if (p.res && !p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+          if constexpr (MODE == 2) {
+            const float4 sl = *reinterpret_cast<const float4*>(p.slope + colc);
+            v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
+            v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+          } else {
+            v.x = apply_act_d(v.x, p.act); v.y = apply_act_d(v.y, p.act); v.z = apply_act_d(v.z, p.act); v.w = apply_act_d(v.w, p.act);
+          }
+          if (p.res && p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+          if (p.gate) { v.x *= gv[it].x; v.y *= gv[it].y; v.z *= gv[it].z; v.w *= gv[it].w; }
+          if (cok && m < p.M) *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + colb) = v;
+        }
+      }
+      return;
+    }
+  #pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + r;
+      const bool cok = col < p.Cout;
+      const float sc = (cok && p.scale) ? p.scale[col] : 1.f;
+      const float sf = (cok && p.shift) ? p.shift[col] : 0.f;
+  #pragma unroll
+      for (int i = 0; i < TM; ++i) {
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int m = m0 + row;
+          if (cok && m < p.M) {
+            float v = acc[i][j][e] * sc + sf;
+            if (p.res && !p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
+            if constexpr (MODE == 2) v = v > 0.f ? v : v * p.slope[col];
+            else v = apply_act_d(v, p.act);
+            if (p.res && p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
+            if (p.gate) v *= p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
+            p.y[(size_t)m * p.ldy + col] = v;
+          }
+        }
+      }
+    }
+  
+    return;
+  } else {
+  // ---- epilogue: transpose through a wave-private LDS region; each lane then owns 4 consecutive channels of a row -----------
+    // Only the accumulator -> LDS writes are unrolled (register indices). The read-back / scale / residual / activation / gate / store
+    // part is a loop over the lane's rows with ONE activation branch per row: fully unrolled with the activation chain (erf, exp,
+    // log1p) inlined per element the epilogue alone was tens of thousands of instructions per kernel - more than the instruction
+    // cache holds - and the 128x128 tile spilled 70 registers in it. 16-byte accesses when legal (p.vec_epi), per-element otherwise.
     constexpr int WC = TN * 32, ES = WC + 4, LPR = WC / 4, RPI = 64 / LPR, NIT = 32 / RPI;
     float* E = smem + wave * 32 * ES;
     const int lr = lane / LPR, lc = (lane % LPR) * 4;
     const int colb = n0 + wn * WC + lc;
+    const bool vec = p.vec_epi != 0;
     const bool cok = colb < p.Cout;
-    const int colc = cok ? colb : 0;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + colc);
-    if (p.shift) sf = *reinterpret_cast<const float4*>(p.shift + colc);
-    // Narrow wave tiles (TN = 1: the 128x64 / 256x32 / 64x64 blocks that carry the HBM-bound short-K layers) fetch the residual
-    // rows of ALL their 32-row slabs up front: TM * NIT <= 8 float4 per lane, twice the bytes in flight while the accumulators
-    // go through the LDS transpose. Wider tiles load per slab (their registers are taken by the accumulators).
-    constexpr bool RES_AHEAD = (TM * NIT <= 8);
-    float4 rall[RES_AHEAD ? TM * NIT : 1];
-    if constexpr (RES_AHEAD) {
-      if (p.res) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int it = 0; it < NIT; ++it) {
-            const int m = m0 + wm * TM * 32 + i * 32 + lr + it * RPI;
-            const int mc = m < p.M ? m : p.M - 1;
-            rall[i * NIT + it] = *reinterpret_cast<const float4*>(p.res + (size_t)mc * p.ldr + colc);
-          }
-      }
+    const bool cfull = colb + 4 <= p.Cout;
+    float sc[4], sf[4], sl[4];
+  #pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool cv = colb + e < p.Cout;
+      sc[e] = (cv && p.scale) ? p.scale[colb + e] : 1.f;
+      sf[e] = (cv && p.shift) ? p.shift[colb + e] : 0.f;
+      sl[e] = (MODE == 2 && cv) ? p.slope[colb + e] : 0.f;
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
-      const int mrow0 = m0 + wm * TM * 32 + i * 32 + lr;
-      float4 rv[NIT], gv[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int m = mrow0 + it * RPI;
-        const int mc = m < p.M ? m : p.M - 1;
-        if constexpr (RES_AHEAD) { if (p.res) rv[it] = rall[i * NIT + it]; }
-        else if (p.res) rv[it] = *reinterpret_cast<const float4*>(p.res + (size_t)mc * p.ldr + colc);
-        if (p.gate) {
-          if (p.gate_c1) { const float g = p.gate[(size_t)mc * p.ldg]; gv[it] = make_float4(g, g, g, g); }
-          else gv[it] = *reinterpret_cast<const float4*>(p.gate + (size_t)mc * p.ldg + colc);
-        }
+    const int act = p.act;
+    auto load4 = [&](const float* base, size_t row_off) -> float4 {
+      if (vec && cfull) return *reinterpret_cast<const float4*>(base + row_off + colb);
+      float w[4];
+  #pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (colb + e < p.Cout) ? base[row_off + colb + e] : 0.f;
+      return make_float4(w[0], w[1], w[2], w[3]);
+    };
+    auto row_of = [&](int i, int it) { return m0 + wm * TM * 32 + i * 32 + lr + it * RPI; };
+    auto fetch_res = [&](int m) -> float4 {
+      const int mc = m < p.M ? m : p.M - 1;
+      return p.res ? load4(p.res, (size_t)mc * p.ldr) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto fetch_gate = [&](int m) -> float4 {
+      const int mc = m < p.M ? m : p.M - 1;
+      if (!p.gate) return make_float4(1.f, 1.f, 1.f, 1.f);
+      if (p.gate_c1) { const float g = p.gate[(size_t)mc * p.ldg]; return make_float4(g, g, g, g); }
+      return load4(p.gate, (size_t)mc * p.ldg);
+    };
+    auto read_row = [&](int erow) -> float4 { return *reinterpret_cast<const float4*>(&E[erow * ES + lc]); };
+    auto finish_row = [&](int m, const float4 v0, const float4 ru, const float4 gu) {
+      float v[4] = {v0.x, v0.y, v0.z, v0.w};
+      const float rf[4] = {ru.x, ru.y, ru.z, ru.w}, gf[4] = {gu.x, gu.y, gu.z, gu.w};
+  #pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = v[e] * sc[e] + sf[e];
+        if (p.res && !p.res_after_act) x += rf[e];
+        v[e] = x;
       }
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int m = mrow0 + it * RPI;
-        float4 v = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc]);
-        v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
-        if (p.res && !p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
-        if constexpr (MODE == 2) {
-          const float4 sl = *reinterpret_cast<const float4*>(p.slope + colc);
-          v.x = v.x > 0.f ? v.x : v.x * sl.x; v.y = v.y > 0.f ? v.y : v.y * sl.y;
-          v.z = v.z > 0.f ? v.z : v.z * sl.z; v.w = v.w > 0.f ? v.w : v.w * sl.w;
+      if constexpr (MODE == 2) {
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
+      } else if (act == ACT_RELU) {
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      } else if (act == ACT_GELU) {
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+      } else if (act == ACT_SIGMOID) {
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+      } else if (act == ACT_SOFTPLUS) {
+  #pragma unroll 1
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 20.f ? v[e] : log1pf(expf(v[e]));
+      }
+  #pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        if (p.res && p.res_after_act) x += rf[e];
+        if (p.gate) x *= gf[e];
+        v[e] = x;
+      }
+      if (cok && m < p.M) {
+        float* yp = p.y + (size_t)m * p.ldy + colb;
+        if (vec) {
+          *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          v.x = apply_act_d(v.x, p.act); v.y = apply_act_d(v.y, p.act); v.z = apply_act_d(v.z, p.act); v.w = apply_act_d(v.w, p.act);
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (colb + e < p.Cout) yp[e] = v[e];
         }
-        if (p.res && p.res_after_act) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
-        if (p.gate) { v.x *= gv[it].x; v.y *= gv[it].y; v.z *= gv[it].z; v.w *= gv[it].w; }
-        if (cok && m < p.M) *reinterpret_cast<float4*>(p.y + (size_t)m * p.ldy + colb) = v;
       }
+    };
+    // Narrow wave tiles (TN = 1: the 128x64 / 256x32 / 64x64 blocks that carry the HBM-bound short-K layers) request the residual and
+    // gate rows of ALL their 32-row slabs before the first transpose (TM * NIT <= 8 float4 each): twice the bytes in flight.
+    constexpr bool AHEAD = (TM * NIT <= 8);
+    float4 rall[AHEAD ? TM * NIT : 1];      // the gate (one layer type of the TOPIQ head) is fetched per row, just in time
+    if constexpr (AHEAD) {
+  #pragma unroll
+      for (int i = 0; i < TM; ++i)
+  #pragma unroll
+        for (int it = 0; it < NIT; ++it) rall[i * NIT + it] = fetch_res(row_of(i, it));
     }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * TN * 32 + j * 32 + r;
-    const bool cok = col < p.Cout;
-    const float sc = (cok && p.scale) ? p.scale[col] : 1.f;
-    const float sf = (cok && p.shift) ? p.shift[col] : 0.f;
-#pragma unroll
+  #pragma unroll
     for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int m = m0 + row;
-        if (cok && m < p.M) {
-          float v = acc[i][j][e] * sc + sf;
-          if (p.res && !p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
-          if constexpr (MODE == 2) v = v > 0.f ? v : v * p.slope[col];
-          else v = apply_act_d(v, p.act);
-          if (p.res && p.res_after_act) v += p.res[(size_t)m * p.ldr + col];
-          if (p.gate) v *= p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
-          p.y[(size_t)m * p.ldy + col] = v;
+  #pragma unroll
+      for (int j = 0; j < TN; ++j)
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
+      if constexpr (AHEAD) {
+        float4 ev[NIT];      // all LDS reads of the slab first: their latency overlaps instead of adding up row by row
+  #pragma unroll
+        for (int it = 0; it < NIT; ++it) ev[it] = read_row(lr + it * RPI);
+  #pragma unroll
+        for (int it = 0; it < NIT; ++it) finish_row(row_of(i, it), ev[it], rall[i * NIT + it], fetch_gate(row_of(i, it)));
+      } else {
+        float4 rn = fetch_res(row_of(i, 0)), gn = fetch_gate(row_of(i, 0));
+  #pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+          const float4 ru = rn, gu = gn;
+          if (it + 1 < NIT) { rn = fetch_res(row_of(i, it + 1)); gn = fetch_gate(row_of(i, it + 1)); }
+          finish_row(row_of(i, it), read_row(lr + it * RPI), ru, gu);
         }
       }
     }
+  
   }
 }
 
