@@ -25,7 +25,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // MODE 0: 3-slab ring + double-buffered fragments (3 waves/SIMD for 64x64 wave tiles).
 // MODE 1: lean - 2 slabs, one fragment set, register budget of 128 so FOUR waves/SIMD are resident.
 // MODE 2: MODE 0 with a PReLU epilogue (per-channel slopes); separate instantiation so the hot tiles keep their registers.
-template <int WGM, int WGN, int TM, int TN, int MODE = 0>
+// ONE_TAP: 1x1 kernels (GEMMs) with Cin % 32 == 0 - no tap masks, the K offset of a slab is the scalar offset of the buffer load.
+template <int WGM, int WGN, int TM, int TN, int MODE = 0, bool ONE_TAP = false>
 __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? 3 : 4)))) void conv_dma_kernel(ConvParams p, const int ntiles) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = 16;
   constexpr int AI = (BM + 63) / 64, BI = (BN + 63) / 64;   // DMA pieces per wave per slab (16 rows x 64 B each)
@@ -249,7 +250,129 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
     __builtin_amdgcn_sched_barrier(0);                                                                             \
   }
 
-  if constexpr (MODE == 1) {
+  // LEAN loop (tiles whose waves all issue the same number of pieces; see kernels_conv_bf16.hip, where the same form was measured
+  // first): unrolled by 6 = ring slot (mod 3) x register set (mod 2), so every LDS read is `base + immediate`, every DMA destination
+  // `base + immediate`, the counted wait an immediate; the last three slabs still issue their pieces, with out-of-range offsets (zero
+  // fill, no memory traffic), so every iteration is the same straight-line code (~45 instead of ~130 instructions around the 16-32
+  // MFMAs of a slab); 1x1 kernels pass the slab's K offset as the scalar offset of the load.
+  constexpr bool LEAN = (MODE != 1) && (BM % 64 == 0) && (BN % 64 == 0) && (TM <= 2) && (TN <= 2);
+  if constexpr (LEAN) {
+    constexpr int NPW = AI + BI;
+    constexpr int SLABB = SLAB * 4;                         // bytes per ring slot
+    const unsigned bA0 = lds_base + (unsigned)((aoff + fo0) * 4), bA1 = lds_base + (unsigned)((aoff + fo1) * 4);
+    const unsigned bB0 = lds_base + (unsigned)((boff + fo0) * 4), bB1 = lds_base + (unsigned)((boff + fo1) * 4);
+    char* const dA = reinterpret_cast<char*>(smem) + 1024 * wave;            // + SLOT * SLABB + 4096 * j
+    char* const dB = reinterpret_cast<char*>(smem) + BM * 64 + 1024 * wave;
+    unsigned aoffs_l[AI];
+#pragma unroll
+    for (int j = 0; j < AI; ++j) aoffs_l[j] = (ONE_TAP && !(amask[j] & 1ull)) ? 0xFFFFFFF0u : aoffs[j];
+    int g3 = 0;                                             // slab being issued
+    int l_tb = 0; bool l_cok = true;
+    auto lean_begin = [&]() {
+      if constexpr (!ONE_TAP) {
+        l_tb = ((kh * p.dh * p.W + kw * p.dw) * p.ldx + ci) * 4;
+        l_cok = ci < p.Cin;
+      }
+    };
+    auto lean_end = [&]() {
+      if constexpr (!ONE_TAP) {
+        ++tap;
+        if (++kw == p.KW) { kw = 0; ++kh; }
+        if (tap == ntaps) { tap = 0; kh = 0; kw = 0; ci += BK; }
+      }
+      ++g3;
+    };
+#define FL_PIECE(SLOT, Q)                                                                                               \
+    {                                                                                                                   \
+      const bool live_ = g3 < nk;                                                                                       \
+      if constexpr ((Q) < AI) {                                                                                         \
+        if constexpr (ONE_TAP) {                                                                                        \
+          const unsigned off_ = live_ ? aoffs_l[(Q) < AI ? (Q) : 0] : 0xFFFFFFF0u;                                      \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dA + (SLOT) * SLABB + 4096 * (Q)), 16, (int)off_, g3 * 64, 0, 0);   \
+        } else {                                                                                                        \
+          const bool ok_ = ((amask[(Q) < AI ? (Q) : 0] >> tap) & 1ull) && l_cok && live_;                                \
+          const unsigned off_ = ok_ ? aoffs[(Q) < AI ? (Q) : 0] + (unsigned)l_tb : 0xFFFFFFF0u;                          \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dA + (SLOT) * SLABB + 4096 * (Q)), 16, (int)off_, 0, 0, 0);         \
+        }                                                                                                               \
+      } else {                                                                                                          \
+        const unsigned off_ = live_ ? boffs[(Q) >= AI ? (Q) - AI : 0] : 0xFFFFFFF0u;                                    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dB + (SLOT) * SLABB + 4096 * ((Q) - AI)), 16, (int)off_, g3 * 64, 0, 0); \
+      }                                                                                                                 \
+    }
+#define FL_READ1(DST, BASE, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "i"(IMM));
+#define FL_READ_FRAGS(SET, SLOT)                                                                                        \
+    {                                                                                                                   \
+      FL_READ1(fa[SET][0], bA0, (SLOT) * SLABB) FL_READ1(fa[SET][1], bA1, (SLOT) * SLABB)                               \
+      if constexpr (TM > 1) { FL_READ1(fa[SET][2], bA0, (SLOT) * SLABB + 2048) FL_READ1(fa[SET][3], bA1, (SLOT) * SLABB + 2048) } \
+      FL_READ1(fb[SET][0], bB0, (SLOT) * SLABB) FL_READ1(fb[SET][1], bB1, (SLOT) * SLABB)                               \
+      if constexpr (TN > 1) { FL_READ1(fb[SET][2], bB0, (SLOT) * SLABB + 2048) FL_READ1(fb[SET][3], bB1, (SLOT) * SLABB + 2048) } \
+    }
+#define FL_MFMA4(SET, Q)                                                                                                \
+    {                                                                                                                   \
+      constexpr int hh_ = (Q) / (TM * TN), i_ = ((Q) / TN) % TM, j_ = (Q) % TN;                                         \
+      acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i_ + hh_].x, fb[SET][2 * j_ + hh_].x, acc[i_][j_], 0, 0, 0); \
+      acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i_ + hh_].y, fb[SET][2 * j_ + hh_].y, acc[i_][j_], 0, 0, 0); \
+      acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i_ + hh_].z, fb[SET][2 * j_ + hh_].z, acc[i_][j_], 0, 0, 0); \
+      acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][2 * i_ + hh_].w, fb[SET][2 * j_ + hh_].w, acc[i_][j_], 0, 0, 0); \
+    }
+#define FL_PIECE_AT(SLOT, N, Q)                                                                                          \
+    if constexpr ((N) < NPW && (((N) + 1) * (2 * TM * TN) / (NPW + 1) - 1 < 0 ? 0 : ((N) + 1) * (2 * TM * TN) / (NPW + 1) - 1) == (Q)) { \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+      FL_PIECE(SLOT, N)                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }
+#define FL_STEP_Q(CUR, SLOTI, Q)                                                                                         \
+    if constexpr ((Q) < 2 * TM * TN) {                                                                                   \
+      FL_MFMA4(CUR, Q)                                                                                                   \
+      FL_PIECE_AT(SLOTI, 0, Q) FL_PIECE_AT(SLOTI, 1, Q) FL_PIECE_AT(SLOTI, 2, Q) FL_PIECE_AT(SLOTI, 3, Q) FL_PIECE_AT(SLOTI, 4, Q) FL_PIECE_AT(SLOTI, 5, Q) \
+    }
+#define FL_SLAB(CUR, NXT, SLOTR, SLOTI)                                                                                  \
+    {                                                                                                                    \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPW) : "memory");                                                         \
+      __builtin_amdgcn_s_barrier();                                                                                      \
+      lean_begin();                                                                                                      \
+      FL_READ_FRAGS(NXT, SLOTR)                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+      FL_STEP_Q(CUR, SLOTI, 0) FL_STEP_Q(CUR, SLOTI, 1) FL_STEP_Q(CUR, SLOTI, 2) FL_STEP_Q(CUR, SLOTI, 3)                \
+      FL_STEP_Q(CUR, SLOTI, 4) FL_STEP_Q(CUR, SLOTI, 5) FL_STEP_Q(CUR, SLOTI, 6) FL_STEP_Q(CUR, SLOTI, 7)                \
+      lean_end();                                                                                                        \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }
+    static_assert(NPW <= 6 && 2 * TM * TN <= 8, "lean loop: piece / MFMA slots");
+#define FL_PIECE_N(SLOT, N) if constexpr ((N) < NPW) FL_PIECE(SLOT, N)
+#define FL_PIECE_ALL(SLOT) FL_PIECE_N(SLOT, 0) FL_PIECE_N(SLOT, 1) FL_PIECE_N(SLOT, 2) FL_PIECE_N(SLOT, 3) FL_PIECE_N(SLOT, 4) FL_PIECE_N(SLOT, 5)
+#define FL_ISSUE_ALL(SLOT) { lean_begin(); FL_PIECE_ALL(SLOT) lean_end(); }
+    FL_ISSUE_ALL(0) FL_ISSUE_ALL(1) FL_ISSUE_ALL(2)         // slab 2 is a dummy when nk == 2
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    FL_READ_FRAGS(0, 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < nk; g += 6) {                       // nk is even (Kp % 32 == 0)
+      FL_SLAB(0, 1, 1, 0)
+      FL_SLAB(1, 0, 2, 1)
+      if (g + 2 < nk) {
+        FL_SLAB(0, 1, 0, 2)
+        FL_SLAB(1, 0, 1, 0)
+      }
+      if (g + 4 < nk) {
+        FL_SLAB(0, 1, 2, 1)
+        FL_SLAB(1, 0, 0, 2)
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the dummy pieces of the tail have landed before the epilogue reuses the ring
+#undef FL_SLAB
+#undef FL_STEP_Q
+#undef FL_PIECE_AT
+#undef FL_MFMA4
+#undef FL_READ_FRAGS
+#undef FL_READ1
+#undef FL_PIECE
+#undef FL_ISSUE_ALL
+#undef FL_PIECE_N
+#undef FL_PIECE_ALL
+  } else if constexpr (MODE == 1) {
     issue(0, 0);
     wait_vm(0);
     __builtin_amdgcn_s_barrier();
@@ -500,14 +623,14 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
   }
 }
 
-template <int WGM, int WGN, int TM, int TN, int MODE = 0>
+template <int WGM, int WGN, int TM, int TN, int MODE = 0, bool ONE_TAP = false>
 static void launch_dma_variant(const ConvParams& p, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
   constexpr size_t main_lds = (size_t)(MODE == 1 ? 2 : 3) * (BM + BN) * 16 * sizeof(float);
   constexpr size_t epi_lds = (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
-  auto kern = conv_dma_kernel<WGM, WGN, TM, TN, MODE>;
+  auto kern = conv_dma_kernel<WGM, WGN, TM, TN, MODE, ONE_TAP>;
   static std::atomic<uint64_t> lds_set{0};
   ensure_dynamic_lds((const void*)kern, lds, lds_set);
   hipLaunchKernelGGL(kern, dim3(mtiles * ntiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, ntiles);
@@ -533,6 +656,14 @@ void launch_conv_dma(const ConvParams& p0, int tile, hipStream_t s) {
       default: launch_dma_variant<2, 2, 2, 2, 2>(p, s); break;
     }
     return;
+  }
+  if (p.KH * p.KW == 1 && p.Cin % 32 == 0 && p.Kp == p.Cin) {   // 1x1 kernels: the lean loop's scalar-offset form
+    switch (tile) {
+      case 1: launch_dma_variant<2, 2, 2, 2, 0, true>(p, s); return;
+      case 7: launch_dma_variant<2, 2, 2, 1, 0, true>(p, s); return;
+      case 4: launch_dma_variant<2, 2, 1, 1, 0, true>(p, s); return;
+      default: break;
+    }
   }
   switch (tile) {
     case 1: launch_dma_variant<2, 2, 2, 2>(p, s); break;
