@@ -328,10 +328,12 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
   if (!no_dma && p.Cin % 16 == 0 && p.KH * p.KW < 64 && xspan < 0xFFFFFF00ull && wspan < 0xFFFFFF00ull) {
     // Tile choice = wave-quantisation model: workgroups are dealt round-robin over the 256 CUs and the ones resident on
     // a CU share its matrix pipes, so a launch lasts ~ ceil(WGs / 256) tiles per CU x (tile area / tile efficiency).
-    // Measured relative efficiencies on the ResNet/ViT shapes (tools/conv_bench.py): 128x128 1.00, 128x64 0.97, 64x64 0.93;
+    // Measured relative efficiencies on the ResNet/ViT shapes (tools/conv_bench.py; re-scanned in round 2): 128x128 1.00, 128x64 1.05, 64x64 0.93;
     // short-K (bandwidth-bound) layers run best on the 128x64 tile (4 waves/SIMD).
     struct Cand { int tile, bm, bn; double eff; };
-    static const Cand wide[3] = {{1, 128, 128, 1.00}, {7, 128, 64, 0.97}, {4, 64, 64, 0.93}};
+    static const double eff7 = getenv("FE_F32_EFF7") ? atof(getenv("FE_F32_EFF7")) : 1.05;   // A/B hook; 0.97 -> 1.05 measured +1 % on TOPIQ with the lean-loop kernels
+    static const int k_short = getenv("FE_F32_KSHORT") ? atoi(getenv("FE_F32_KSHORT")) : 256;
+    const Cand wide[3] = {{1, 128, 128, 1.00}, {7, 128, 64, eff7}, {4, 64, 64, 0.93}};
     static const Cand narrow[2] = {{7, 128, 64, 1.00}, {4, 64, 64, 0.95}};
     int tile = 3;
     if (p.Cout > 32) {
@@ -339,7 +341,7 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
       const int nc = p.Cout > 64 ? 3 : 2;
       double best = 1e300;
       for (int i = 0; i < nc; ++i) {
-        if (p.Cout > 64 && p.K <= 256 && cs[i].tile == 1) continue;
+        if (p.Cout > 64 && p.K <= k_short && cs[i].tile == 1) continue;
         const long long wgs = (long long)((p.M + cs[i].bm - 1) / cs[i].bm) * ((p.Cout + cs[i].bn - 1) / cs[i].bn) * q.batch;
         const double cost = (double)((wgs + 255) / 256) * cs[i].bm * cs[i].bn / cs[i].eff;
         if (cost < best) { best = cost; tile = cs[i].tile; }
