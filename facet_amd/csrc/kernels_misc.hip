@@ -158,10 +158,40 @@ __global__ void bilinear_kernel(const T* __restrict__ x, int ldx, T* __restrict_
     stf(y + ((img * ho + oh) * wo + ow) * ldy + ch, hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
   }
 }
+// 4 channels per thread (8- / 16-byte accesses); same arithmetic per element as the scalar kernel
+template <class T>
+__global__ void bilinear_vec4_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int n, int h, int w,
+                                     int c4, int ho, int wo, float sy, float sx) {
+  const size_t total = (size_t)n * ho * wo * c4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c4) * 4;
+    size_t pix = i / c4;
+    const int ow = pix % wo; pix /= wo;
+    const int oh = pix % ho;
+    const size_t img = pix / ho;
+    float fy = ((float)oh + 0.5f) * sy - 0.5f; if (fy < 0.f) fy = 0.f;
+    float fx = ((float)ow + 0.5f) * sx - 0.5f; if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const T* b = x + img * h * w * ldx + ch;
+    const float4 v00 = ld4(b + ((size_t)y0 * w + x0) * ldx), v01 = ld4(b + ((size_t)y0 * w + x1) * ldx);
+    const float4 v10 = ld4(b + ((size_t)y1 * w + x0) * ldx), v11 = ld4(b + ((size_t)y1 * w + x1) * ldx);
+    st4(y + ((img * ho + oh) * wo + ow) * ldy + ch,
+        make_float4(hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x), hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y),
+                    hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z), hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w)));
+  }
+}
 template <class T>
 void launch_bilinear(const TensorT<T>& x, const TensorT<T>& y, hipStream_t s) {
   FE_CHECK(x.c == y.c && x.n == y.n, "bilinear: shape mismatch");
   const float sy = (float)x.h / (float)y.h, sx = (float)x.w / (float)y.w;
+  if (x.c % 4 == 0 && x.ld % 4 == 0 && y.ld % 4 == 0 && vec4_ok(x.p, y.p)) {
+    hipLaunchKernelGGL(bilinear_vec4_kernel<T>, dim3(grid_for(y.pixels() * (size_t)(y.c / 4))), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c / 4, y.h, y.w, sy, sx);
+    FE_HIP(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(bilinear_kernel<T>, dim3(grid_for(y.numel())), dim3(256), 0, s, x.p, x.ld, y.p, y.ld, x.n, x.h, x.w, x.c, y.h, y.w, sy, sx);
   FE_HIP(hipGetLastError());
 }
@@ -440,11 +470,57 @@ __global__ void layernorm_kernel(const T* __restrict__ x, int ldx, T* __restrict
     for (int i = lane; i < d; i += 64) stf(yr + i, (ldf(xr + i) - mean) * rstd * g[i] + b[i]);
   }
 }
+// Register-resident form for d = 256 * NV (the ViT / CFANet widths 256, 768, 1024): one wave per row, every lane holds 4 * NV
+// consecutive-by-256 elements (8- or 16-byte loads: whole 512-B / 1-KiB segments per wave instruction), ONE read and one write of
+// the row; mean, then centred variance, both in fp32 registers.
+template <class T, int NV>
+__global__ void layernorm_reg_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                     const float* __restrict__ g, const float* __restrict__ b, int rows, float eps) {
+  constexpr int d = 256 * NV;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  float4 gv[NV], bv[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    gv[k] = *reinterpret_cast<const float4*>(g + 256 * k + 4 * lane);
+    bv[k] = *reinterpret_cast<const float4*>(b + 256 * k + 4 * lane);
+  }
+  for (int row = wave; row < rows; row += nwaves) {
+    const T* xr = x + (size_t)row * ldx;
+    float4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { v[k] = ld4(xr + 256 * k + 4 * lane); sum += (v[k].x + v[k].y) + (v[k].z + v[k].w); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)d;
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+      var += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)d + eps);
+    T* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      st4(yr + 256 * k + 4 * lane, make_float4(v[k].x * rstd * gv[k].x + bv[k].x, v[k].y * rstd * gv[k].y + bv[k].y,
+                                               v[k].z * rstd * gv[k].z + bv[k].z, v[k].w * rstd * gv[k].w + bv[k].w));
+  }
+}
 template <class T>
 void launch_layernorm(const T* x, int ldx, T* y, int ldy, const float* g, const float* b, int rows, int d,
                       float eps, hipStream_t s) {
   const int blocks = grid_for((size_t)rows * 64);
-  hipLaunchKernelGGL(layernorm_kernel<T>, dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, d, eps);
+  const bool vec = d % 256 == 0 && d <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && vec4_ok(x, y) && ((((uintptr_t)g | (uintptr_t)b) & 15) == 0);
+  if (vec && d == 256) hipLaunchKernelGGL((layernorm_reg_kernel<T, 1>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  else if (vec && d == 512) hipLaunchKernelGGL((layernorm_reg_kernel<T, 2>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  else if (vec && d == 768) hipLaunchKernelGGL((layernorm_reg_kernel<T, 3>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  else if (vec && d == 1024) hipLaunchKernelGGL((layernorm_reg_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  else hipLaunchKernelGGL(layernorm_kernel<T>, dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, d, eps);
   FE_HIP(hipGetLastError());
 }
 

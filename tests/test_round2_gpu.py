@@ -135,7 +135,7 @@ N, H, W = int(os.environ["FACET_N"]), 160, 192
 torch.cuda.set_device(0)
 if world > 1:
     dist.init_process_group("gloo")          # two ranks share the one GPU of the test box; the real run is nccl, one GPU per rank
-eng = Engine(0, arena_bytes=6 << 30)
+eng = Engine(0, arena_bytes=6 << 30, precision=os.environ.get("FACET_PREC", "f32"))
 for mid, name in ((FE_MODEL_TOPIQ, "topiq"), (FE_MODEL_CLIP, "clip"), (FE_MODEL_AESTHETIC, "aesthetic"), (FE_MODEL_U2NETP, "u2netp"),
                   (FE_MODEL_SAMP, "samp_net")):
     eng.load_weights(mid, synthetic_state_dict(name, 13))
@@ -157,17 +157,18 @@ print(json.dumps({"rank": rank, "shape": list(rec.shape), "mask": mask}))
 '''
 
 
-@pytest.mark.parametrize("n_items", [6, 5])
-def test_two_ranks_score_their_shards_and_gather_the_single_rank_result(tmp_path, n_items):
+@pytest.mark.parametrize("n_items,prec", [(6, "f32"), (5, "f32"), (5, "bf16")])
+def test_two_ranks_score_their_shards_and_gather_the_single_rank_result(tmp_path, n_items, prec):
     """Engine-level N > 1 run: two fresh processes (gloo, both on GPU 0) each score their shard_range block through
     fe_ensemble_score_dev + fe_face_analyze, all-gather the fixed-size records (789 + 1 + 2 x 739 floats) and must end up with
-    exactly the rows a single rank computes for the whole batch - also for a ragged N (5 = 3 + 2)."""
+    exactly the rows a single rank computes for the whole batch - also for a ragged N (5 = 3 + 2), and with the models committed in
+    bf16 (BASELINE configs[3]: the 16gb profile in bf16 sharded across ranks; the face graphs stay fp32)."""
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     base.update(FACET_ROOT=ROOT, FACET_OUT=str(tmp_path), FACET_N=str(n_items), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                HSA_ENABLE_IPC_MODE_LEGACY="0")
+                HSA_ENABLE_IPC_MODE_LEGACY="0", FACET_PREC=prec)
     one = subprocess.run([sys.executable, str(script)], env=dict(base, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(base, RANK=str(r), WORLD_SIZE="2"), stdout=subprocess.PIPE,
@@ -181,6 +182,8 @@ def test_two_ranks_score_their_shards_and_gather_the_single_rank_result(tmp_path
     assert np.array_equal(r0, r1)                       # every rank holds the same gathered table
     # row for row the single-rank result. The towers batch their crops per call, so a shard sees other chunk boundaries than the
     # whole batch: identical up to fp32 summation order inside the GEMM tiles, not bit-identical
-    assert np.abs(r0 - single).max() <= 5e-5 * max(1.0, np.abs(single).max()), float(np.abs(r0 - single).max())
+    # (bf16: a crop that moves to another position of a tower batch meets other tile boundaries and rounds differently - 8 bits)
+    tol = 5e-5 if prec == "f32" else 2e-2
+    assert np.abs(r0 - single).max() <= tol * max(1.0, np.abs(single).max()), float(np.abs(r0 - single).max())
     assert np.array_equal(r0[:, FE_RECORD_FLOATS], single[:, FE_RECORD_FLOATS])      # face counts
     assert json.loads(one.stdout.strip().splitlines()[-1])["mask"] == 7
