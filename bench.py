@@ -251,7 +251,7 @@ def main():
         need_mask |= WL[w][0]
     need_faces = any(WL[w][1] for w in need)
 
-    def make_engine(precision, mask, faces):
+    def make_engine(precision, mask):
         e = Engine(dev_index, arena_bytes=(4 + 2 * args.microbatch * max(1, (HW * HW) // (1024 * 1024))) << 30, precision=precision)
         e.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", seed=3))
         if mask & 2:
@@ -260,22 +260,29 @@ def main():
         if mask & 4:
             e.load_weights(FE_MODEL_U2NETP, synthetic_state_dict("u2netp", seed=3))
             e.load_weights(FE_MODEL_SAMP, synthetic_state_dict("samp_net", seed=3))
-        if faces:
-            # BASELINE.json configs[2] / the metric's InsightFace stage. Seeded stand-in graphs of the buffalo_l architectures
-            # (no model files offline); uniform-noise images carry no real faces, so the best FACES_PER_IMAGE detections of the
-            # synthetic detector go through landmarks + ArcFace (fixed faces-per-image mode).
-            from standins import synthetic_onnx as SO
-            from facet_amd._lib import FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC
-            e.graph_load(FE_GRAPH_FACE_DET, SO.scrfd_like(seed=12, size=640)[0])
-            e.graph_load(FE_GRAPH_FACE_LMK, SO.landmark_like(seed=13)[0])
-            e.graph_load(FE_GRAPH_FACE_REC, SO.arcface_iresnet(seed=14)[0])
         e.set_microbatch(args.microbatch)
         return e
 
-    eng = make_engine(args.dtype, need_mask, need_faces)
+    def make_face_engine():
+        # BASELINE.json configs[2] / the metric's InsightFace stage. Seeded stand-in graphs of the buffalo_l architectures
+        # (no model files offline); uniform-noise images carry no real faces, so the best FACES_PER_IMAGE detections of the
+        # synthetic detector go through landmarks + ArcFace (fixed faces-per-image mode). The stage owns a
+        # context (stream + arena) of its own: its host glue (NMS, alignment matrices) sits between its launches, so
+        # score_shard runs it in a worker thread beside the ensemble's launches, as BatchScorer does with aux_engine.
+        from standins import synthetic_onnx as SO
+        from facet_amd._lib import FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC
+        e = Engine(dev_index, arena_bytes=(4 + args.microbatch // 2) << 30)
+        e.graph_load(FE_GRAPH_FACE_DET, SO.scrfd_like(seed=12, size=640)[0])
+        e.graph_load(FE_GRAPH_FACE_LMK, SO.landmark_like(seed=13)[0])
+        e.graph_load(FE_GRAPH_FACE_REC, SO.arcface_iresnet(seed=14)[0])
+        e.set_microbatch(args.microbatch)
+        return e
+
+    eng = make_engine(args.dtype, need_mask)
+    face_eng = make_face_engine() if need_faces else None
     engines = {args.dtype: eng}
     if not (args.no_sub or world > 1) and args.dtype == "f32":
-        engines["bf16"] = make_engine("bf16", 7, False)     # second context for the configs[3] sub-measurement
+        engines["bf16"] = make_engine("bf16", 7)     # second context for the configs[3] sub-measurement
 
     # this rank's shard of the global batch (weak scaling: B images per GPU), generated once, resident in HBM
     lo, hi = shard_range(B * world, world, rank)
@@ -303,7 +310,7 @@ def main():
 
         def step():
             # records are written into a device buffer, all-gathered in place (RCCL) and copied to the host once
-            rec, ran = score_shard(eng, images, B * world, world, rank, faces=fargs)
+            rec, ran = score_shard(eng, images, B * world, world, rank, faces=fargs, face_engine=face_eng if faces else None)
             assert ran == mask, (ran, mask)
             return rec
         return step
@@ -314,6 +321,8 @@ def main():
         for _ in range(warmup):
             step()
         eng.flops_reset()
+        if face_eng is not None:
+            face_eng.flops_reset()
         barrier()
         eng.timer_start()
         t0 = time.perf_counter()
@@ -326,7 +335,10 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), ev_ms, eng.flops(), eng.flops_executed()
+        fl, fx = eng.flops(), eng.flops_executed()
+        if face_eng is not None and WL[wl][1]:
+            fl, fx = fl + face_eng.flops(), fx + face_eng.flops_executed()      # the face graphs' contractions run on the other context
+        return float(t.item()), ev_ms, fl, fx
 
     def per_launch(wl, eng):
         """Per-launch view of the dominant kernel family (rank 0, outside the timed region): one micro-batch with a HIP event pair
@@ -407,7 +419,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.dev_free(d_imgs)
-    for e in engines.values():
+    for e in list(engines.values()) + ([face_eng] if face_eng is not None else []):
         e.close()
 
 

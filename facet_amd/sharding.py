@@ -68,11 +68,25 @@ def gather_device(local_t, world):
     return out
 
 
-def score_shard(engine, images, n_items, world, rank, faces=None, record_floats=789):
+_face_pool = None
+
+
+def _face_worker():
+    global _face_pool
+    if _face_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _face_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="facet-faces")
+    return _face_pool
+
+
+def score_shard(engine, images, n_items, world, rank, faces=None, record_floats=789, face_engine=None):
     """One multi-GPU step of the ensemble for this rank's contiguous block of a global batch of n_items images: `images` is the
     rank's (device_ptr, n, h, w) block (n = hi - lo of shard_range). Records are produced in a device buffer padded to the largest
     shard, gathered once, and returned as a host array [n_items, R] in global image order (identical on every rank).
-    faces: None, or (det_size, det_thresh, nms_thresh, max_faces) to append [count, max_faces x 739 face slots] per image."""
+    faces: None, or (det_size, det_thresh, nms_thresh, max_faces) to append [count, max_faces x 739 face slots] per image.
+    face_engine: a second Engine (own context and stream on the same device) holding the face graphs; the face stage, whose NMS /
+    alignment glue runs on the host between launches, then runs in a worker thread beside the ensemble instead of after it (the same
+    arrangement as BatchScorer's aux_engine). Results are identical either way."""
     import torch
     from ._lib import FE_FACE_FLOATS
     lo, hi = shard_range(n_items, world, rank)
@@ -84,9 +98,17 @@ def score_shard(engine, images, n_items, world, rank, faces=None, record_floats=
     mask = 0
     if n:
         assert images[1] == n, (images[1], lo, hi)
-        mask = engine.ensemble_score_dev(images, rec.data_ptr(), R)
+        fut = None
+        if faces and face_engine is not None and face_engine is not engine:
+            fut = _face_worker().submit(face_engine.face_analyze, images, faces[0], faces[1], faces[2], faces[3])
+        try:
+            mask = engine.ensemble_score_dev(images, rec.data_ptr(), R)
+        except BaseException:
+            if fut is not None:
+                fut.exception()            # never leave the worker running against buffers the caller may free
+            raise
         if faces:
-            f, counts, _ = engine.face_analyze(images, faces[0], faces[1], faces[2], faces[3])
+            f, counts, _ = fut.result() if fut is not None else engine.face_analyze(images, faces[0], faces[1], faces[2], faces[3])
             extra = np.concatenate([counts[:, None].astype(np.float32), f.reshape(n, -1)], axis=1)
             rec[:n, record_floats:] = torch.from_numpy(extra).to(dev)      # the face glue runs on the host: a few KB per image go up
     full = gather_device(rec, world).cpu().numpy()

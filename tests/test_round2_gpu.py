@@ -139,20 +139,26 @@ eng = Engine(0, arena_bytes=6 << 30, precision=os.environ.get("FACET_PREC", "f32
 for mid, name in ((FE_MODEL_TOPIQ, "topiq"), (FE_MODEL_CLIP, "clip"), (FE_MODEL_AESTHETIC, "aesthetic"), (FE_MODEL_U2NETP, "u2netp"),
                   (FE_MODEL_SAMP, "samp_net")):
     eng.load_weights(mid, synthetic_state_dict(name, 13))
-eng.graph_load(FE_GRAPH_FACE_DET, SO.scrfd_like(seed=12, size=160)[0])
-eng.graph_load(FE_GRAPH_FACE_LMK, SO.landmark_like(seed=13)[0])
-eng.graph_load(FE_GRAPH_FACE_REC, SO.arcface_iresnet(layers=(1, 1, 1, 1), seed=14)[0])
-eng.set_microbatch(2)
+# the sharded ranks keep the face graphs on a second context that runs beside the ensemble (score_shard face_engine, what bench.py
+# does); the single rank runs them on the one context, after the ensemble: the rows must not depend on that
+feng = Engine(0, arena_bytes=2 << 30) if world > 1 else eng
+feng.graph_load(FE_GRAPH_FACE_DET, SO.scrfd_like(seed=12, size=160)[0])
+feng.graph_load(FE_GRAPH_FACE_LMK, SO.landmark_like(seed=13)[0])
+feng.graph_load(FE_GRAPH_FACE_REC, SO.arcface_iresnet(layers=(1, 1, 1, 1), seed=14)[0])
+eng.set_microbatch(2); feng.set_microbatch(2)
 imgs = synthetic_images(31, N, H, W)          # the GLOBAL batch; every rank uploads only its contiguous block
 lo, hi = shard_range(N, world, rank)
 d = eng.dev_alloc(max(1, hi - lo) * H * W * 3)
 if hi > lo:
     eng.h2d(d, imgs[lo:hi])
-rec, mask = score_shard(eng, (d, hi - lo, H, W), N, world, rank, faces=((160, 160), 0.3, 0.4, 2))
+rec, mask = score_shard(eng, (d, hi - lo, H, W), N, world, rank, faces=((160, 160), 0.3, 0.4, 2), face_engine=feng)
 np.save(os.path.join(os.environ["FACET_OUT"], f"rec_w{world}_r{rank}.npy"), rec)
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
-eng.dev_free(d); eng.close()
+eng.dev_free(d)
+if feng is not eng:
+    feng.close()
+eng.close()
 print(json.dumps({"rank": rank, "shape": list(rec.shape), "mask": mask}))
 '''
 
