@@ -46,6 +46,9 @@ WL = {"topiq": (1, False), "topiq_clip": (3, False), "ensemble": (7, False), "fa
 
 def workload_text(wl, B, HW, dtype="f32"):
     t = _workload_text(wl, B, HW)
+    if dtype == "clip_bf16":
+        return t.replace("CLIP ViT-L/14 + aesthetic MLP", "CLIP ViT-L/14 in bf16 (the reference halves CLIP on a GPU, processing/scorer.py:513-516; "
+                         "aesthetic MLP fp32 on the fp32 features as there)")
     if dtype == "bf16":
         t = t.replace(" fp32", " bf16 (bf16 activations / weights, fp32 accumulate, fp32 first layers + LayerNorm / softmax statistics + score heads)")
         if wl == "ensemble":
@@ -251,12 +254,16 @@ def main():
         need_mask |= WL[w][0]
     need_faces = any(WL[w][1] for w in need)
 
-    def make_engine(precision, mask):
+    def make_engine(precision, mask, clip_precision=None):
         e = Engine(dev_index, arena_bytes=(4 + 2 * args.microbatch * max(1, (HW * HW) // (1024 * 1024))) << 30, precision=precision)
         e.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", seed=3))
         if mask & 2:
+            if clip_precision:
+                e.set_precision(clip_precision)      # precision is a property of a model's committed weights
             e.load_weights(FE_MODEL_CLIP, synthetic_state_dict("clip", seed=3))
             e.load_weights(FE_MODEL_AESTHETIC, synthetic_state_dict("aesthetic", seed=3))
+            if clip_precision:
+                e.set_precision(precision)
         if mask & 4:
             e.load_weights(FE_MODEL_U2NETP, synthetic_state_dict("u2netp", seed=3))
             e.load_weights(FE_MODEL_SAMP, synthetic_state_dict("samp_net", seed=3))
@@ -381,6 +388,22 @@ def main():
                         "convolution's (algorithmic) FLOPs by the same time",
                 "event_ms": round(ev_ms, 3), "per_launch": per_launch(wl, eng) if rank == 0 else None}
 
+    def mixed_roofline(steps, ev_ms, flops, flops_exec, eng):
+        """fp32 models + bf16 CLIP: the matrix pipes' busy time at peak is F32 / peak32 + F16 / peak16; frac = that over the measured time."""
+        eng.ensemble_select(2)
+        eng.flops_reset()
+        eng.ensemble_score((d_imgs, min(B, args.microbatch), HW, HW))
+        clip_fx = eng.flops_executed() / min(B, args.microbatch) * B * steps      # CLIP's executed FLOPs in the timed region
+        eng.ensemble_select(7)
+        t = ev_ms * 1e-3
+        pipe_s = (flops_exec - clip_fx) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + clip_fx / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+        return {"bound": "mfma", "achieved": round(flops_exec / t / 1e12, 2), "unit": "TFLOP/s",
+                "peak": {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS},
+                "frac": round(pipe_s / t, 4), "traffic": None,
+                "executed_flops_per_image": {"f32": round((flops_exec - clip_fx) / (B * steps), 1), "bf16": round(clip_fx / (B * steps), 1)},
+                "note": "two dtypes share the launch stream: frac = (fp32 FLOPs / fp32 MFMA peak + bf16 FLOPs / bf16 MFMA peak) / measured time",
+                "event_ms": round(ev_ms, 3)}
+
     dt_max, ev_ms, flops, flops_exec = measure(primary, args.steps, args.warmup, eng)
     out = None
     if rank == 0:
@@ -401,14 +424,19 @@ def main():
     sub_runs = [(wl, wl, args.dtype) for wl in subs]
     if "bf16" in engines and args.dtype == "f32":
         sub_runs.append(("ensemble_bf16", "ensemble", "bf16"))      # BASELINE configs[3] on one GPU
+        if primary == "full":
+            sub_runs.append(("full_clip_bf16", "full", "clip_bf16"))    # the reference's own GPU precisions: CLIP halved, the rest fp32
     for key, wl, dt in sub_runs:
         s_steps, s_warm = 3, 1
+        if dt == "clip_bf16":
+            engines.pop("bf16").close()          # one spare context at a time: each holds an arena of tens of GB
+            engines[dt] = make_engine("f32", 7, clip_precision="bf16")
         e = engines[dt]
         dts, evs, fl, fx = measure(wl, s_steps, s_warm, e)
         sub[key] = {"value": round(B * s_steps / dts, 2), "unit": "images/s", "steps": s_steps, "warmup": s_warm,
-                    "ms_per_step": round(dts / s_steps * 1e3, 3), "dtype": dt,
+                    "ms_per_step": round(dts / s_steps * 1e3, 3), "dtype": "f32 + bf16 CLIP" if dt == "clip_bf16" else dt,
                     "config": {"workload": workload_text(wl, B, HW, dt)},
-                    "roofline": roofline(wl, s_steps, evs, fl, fx, e, dt)}
+                    "roofline": mixed_roofline(s_steps, evs, fl, fx, e) if dt == "clip_bf16" else roofline(wl, s_steps, evs, fl, fx, e, dt)}
     if rank == 0:
         if sub:
             out["sub"] = sub

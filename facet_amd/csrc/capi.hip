@@ -106,13 +106,21 @@ class ImageStager {
   if (!(ctx)) return FE_ERR_INVALID;              \
   try {                                           \
     (void)hipSetDevice((ctx)->c.device);
+// On the error path nothing may stay in flight: queued async copies read the caller's host buffers and write into host
+// vectors local to the entry point, both of which die when it returns.
+static void fe_drain(fe_ctx* ctx);
 #define FE_API_END(ctx)                           \
   }                                               \
   catch (const std::exception& e) {               \
     (ctx)->c.err = e.what();                      \
+    fe_drain(ctx);                                \
     return FE_ERR_RUNTIME;                        \
   }                                               \
   return FE_OK;
+static void fe_drain(fe_ctx* ctx) {
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  if (ctx->c.stream) (void)hipStreamSynchronize(ctx->c.stream);
+}
 
 extern "C" {
 

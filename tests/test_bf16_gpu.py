@@ -206,3 +206,32 @@ def test_ensemble_bf16_records_against_fp32_engine(eng16, engine):
         assert cos.min() > 0.999
         assert np.abs(r16[:, 2:10] - r32[:, 2:10]).max() < 3e-2 * max(1.0, np.abs(r32[:, 2:10]).max())
         assert np.abs(r16[:, 10:21] - r32[:, 10:21]).max() < 3e-2
+
+
+def test_clip_in_bf16_beside_fp32_models_in_one_context(eng16, engine):
+    """The reference's own GPU precisions (processing/scorer.py:513-516 halves CLIP only): precision is a property of a model's
+    committed weights, so one context can hold CLIP in bf16 beside TOPIQ / SAMP-Net in fp32. Every field of the record must then be
+    exactly what the context of that field's precision produces on its own."""
+    from facet_amd import Engine
+    names = ["topiq", "clip", "aesthetic", "u2netp", "samp_net"]
+    _load(eng16, names, 13)
+    _load(engine, names, 13)
+    mixed = Engine(0, arena_bytes=8 << 30)
+    try:
+        _load(mixed, ["topiq", "u2netp", "samp_net"], 13)
+        mixed.set_precision("bf16")
+        _load(mixed, ["clip", "aesthetic"], 13)
+        mixed.set_precision("f32")
+        assert mixed.model_precision(FE_MODEL_CLIP) == "bf16" and mixed.model_precision(FE_MODEL_TOPIQ) == "f32"
+        assert mixed.model_precision(FE_MODEL_SAMP) == "f32" and mixed.model_precision(FE_MODEL_U2NETP) == "f32"
+        imgs = synthetic_images(9, 3, 224, 320)
+        for e in (mixed, eng16, engine):
+            e.set_microbatch(2)
+        rm, mm = mixed.ensemble_score(imgs)
+        r16, _ = eng16.ensemble_score(imgs)
+        r32, _ = engine.ensemble_score(imgs)
+        assert mm == 7
+        assert np.array_equal(rm[:, 0], r32[:, 0]) and np.array_equal(rm[:, 2:21], r32[:, 2:21])      # TOPIQ, SAMP-Net: the fp32 path
+        assert np.array_equal(rm[:, 1], r16[:, 1]) and np.array_equal(rm[:, 21:], r16[:, 21:])        # aesthetic, embedding: the bf16 tower
+    finally:
+        mixed.close()
