@@ -65,7 +65,7 @@ __device__ __forceinline__ float fe_apply_act_fast(float v, int act) {   // bf16
   if (act == ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == ACT_GELU) return 0.5f * v * (1.f + fe_erf_fast(v * 0.70710678118654752440f));
   if (act == ACT_SIGMOID) return __frcp_rn(1.f + __expf(-v));
-  if (act == ACT_SOFTPLUS) return v > 20.f ? v : log1pf(expf(v));
+  if (act == ACT_SOFTPLUS) return fmaxf(v, 0.f) + __logf(1.f + __expf(-fabsf(v)));   // |error| ~1e-7: far below the bf16 rounding of the result
   return v;
 }
 
@@ -176,6 +176,7 @@ struct ConvParamsT {
   int batch, nb1;
   long long xs1, xs2, ws1, ws2, ys1, ys2, hs1;   // hs1: shift stride per inner index
   int buf_ok; unsigned x_span, w_span;  // set by launch_conv_dma: operands addressable through 32-bit buffer offsets
+  unsigned y_span, r_span, g_span;      // set by launch_conv_bf16: byte spans of y / res / gate (0: beyond 32-bit buffer addressing)
   int variant;                      // 0 = auto tile choice; >0 forces a tile variant (tools/conv_bench.py)
   int cb;                           // bf16 kernel: channel block of the packed K order (32, or 16 for Cin % 32 != 0 spatial kernels)
   int pad_store;                    // bf16 kernel: columns [Cout, roundup8(Cout)) exist in y and are written as zeros (V^T GEMM)

@@ -16,7 +16,8 @@
 //     channel-in-block innermost. With cb = 16 a slab holds TWO (block, tap) units: lanes pick theirs by the half of the slab
 //     their 16-B chunk lies in. 1x1 kernels (GEMMs) take any Cin % 8 == 0: the chunk past Cin is fetched as zeros;
 //   * padding taps / rows past M / chunks past Cin = out-of-range buffer offsets (the hardware returns zeros);
-//   * epilogue through a wave-private LDS transpose to 16-byte (8 x bf16) row stores.
+//   * epilogue: narrow wave tiles (TN = 1) through a wave-private LDS transpose to 16-byte (8 x bf16) row stores; wide wave tiles
+//     (TN = 2) swap the MFMA operands so the accumulators come out transposed and finish in registers (h_epilogue_wide).
 #include "fe_common.h"
 #include <cstdlib>
 
@@ -40,10 +41,115 @@ __device__ __forceinline__ void h_unpack8(const uint4 u, float v[8]) {
   v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xFFFF0000u);
 }
 
+
+// Epilogue of the wide wave tiles (TN >= 2). Their MFMAs take the operands SWAPPED (weights as the row operand): the accumulator of a
+// 32x32 tile then holds, in lane (r, h), pixel row r and the channels 8g + 4h + {0..3} (g = 0..3) - four CONSECUTIVE channels per
+// register quad. Scale / shift / residual / activation / the rounding to bf16 all run on the registers, straight-line: every global
+// access is a buffer load whose offset is pushed out of range for rows past M and columns past Cout (reads return zeros), so the
+// math is ONE basic block and the compiler hoists its loads. The packed quads (8 bytes) then go through a wave-private LDS image of
+// the wave tile, row-major, and leave as 16-byte stores, eight lanes per 128-byte row: written straight from the registers each
+// store instruction would touch 32 rows with 16 bytes each, and the L2 takes a request per row segment, not per byte (measured on
+// the ViT-L/14 GEMMs: 8-byte register stores 642-790 TFLOP/s, the same kernels with the stores dropped 836-1000).
+// The transposing fp32 epilogue these tiles had before ran NIT dependent LDS round trips and residual fetches per 32 rows.
+// ACTK: 0 none, 1 ReLU, 2 GELU, -1 the activation named by p.act; GATE: multiplicative gate (TOPIQ GatedConv); the residual is added
+// before the activation unless p.res_after_act. launch_conv_bf16 picks a wide tile only where the 16-byte vector layout is legal
+// (p.vec_epi) and y / res / gate span less than 4 GB.
+typedef unsigned h_v2u __attribute__((ext_vector_type(2)));
+typedef unsigned h_v4u __attribute__((ext_vector_type(4)));
+typedef float h_v4 __attribute__((ext_vector_type(4)));
+template <int TM, int TN, int ACTK, bool RES, bool GATE>
+__device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const ConvParamsH& p, const int row0, const int col0,
+                                                const int lane, char* const stage) {
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  constexpr int PITCH = TN * 64 + 16;          // bytes per staged row: TN * 32 bf16 + 16 (conflict-free 8-byte writes, 16-byte aligned reads)
+  const int r = lane & 31, h = lane >> 5;
+  const int mb = row0 + r;                     // the lane's pixel row of tile row i: mb + 32 i
+  const int cb = col0 + 4 * h;                 // its first channel of tile column j, quad g: cb + 32 j + 8 g
+  const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
+  const bool hs = p.scale != nullptr, hb = p.shift != nullptr;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(RES ? p.res : p.y), 0, RES ? (int)p.r_span : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(GATE ? p.gate : p.y), 0, GATE ? (int)p.g_span : 0, 0x00020000);
+  // a null scale / shift becomes an empty buffer: every read returns 0
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hs ? p.scale : p.shift), 0, hs ? p.Cout * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb ? p.shift : p.scale), 0, hb ? p.Cout * 4 : 0, 0x00020000);
+  bool rok[TM];
+  unsigned rbo[TM], gbo[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mb + 32 * i;
+    rok[i] = m < p.M;
+    rbo[i] = RES ? (unsigned)m * (unsigned)(p.ldr * 2) : 0u;
+    gbo[i] = GATE ? (unsigned)m * (unsigned)(p.ldg * 2) : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    h_v4 sc[4], sf[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {      // Cout % 8 == 0 wherever a scale or shift exists (p.vec_epi): a quad is wholly inside or outside
+      const int c0 = cb + 32 * j + 8 * g;
+      const unsigned co = c0 < p.Cout ? (unsigned)c0 * 4u : OOB;
+      sc[g] = __builtin_bit_cast(h_v4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)co, 0, 0));
+      sf[g] = __builtin_bit_cast(h_v4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)co, 0, 0));
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c0 = cb + 32 * j + 8 * g;
+      h_v2u ru[TM], gu[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (RES) ru[i] = __builtin_amdgcn_raw_buffer_load_b64(rr, (int)((rok[i] && c0 < p.Cout) ? rbo[i] + (unsigned)c0 * 2u : OOB), 0, 0);
+        if (GATE) {
+          if (p.gate_c1) gu[i].x = gu[i].y = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rg, (int)(rok[i] ? gbo[i] : OOB), 0, 0) * 0x10001u;
+          else gu[i] = __builtin_amdgcn_raw_buffer_load_b64(rg, (int)((rok[i] && c0 < p.Cout) ? gbo[i] + (unsigned)c0 * 2u : OOB), 0, 0);
+        }
+      }
+      float s4[4], b4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {        // no scale: 1 inside Cout, 0 past it (the zero columns of a pad_store row)
+        s4[e] = hs ? sc[g][e] : (c0 + e < p.Cout ? 1.f : 0.f);
+        b4[e] = sf[g][e];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[i][j][4 * g + e] * s4[e] + b4[e];
+          float rf = 0.f;
+          if (RES) rf = __uint_as_float((e & 1) ? ((e < 2 ? ru[i].x : ru[i].y) & 0xFFFF0000u) : ((e < 2 ? ru[i].x : ru[i].y) << 16));
+          if (RES && !p.res_after_act) x += rf;
+          if (ACTK == 1) x = x > 0.f ? x : 0.f;
+          else if (ACTK == 2) x = 0.5f * x * (1.f + fe_erf_fast(x * 0.70710678118654752440f));
+          else if (ACTK < 0) x = fe_apply_act_fast(x, p.act);
+          if (RES && p.res_after_act) x += rf;
+          if (GATE) x *= __uint_as_float((e & 1) ? ((e < 2 ? gu[i].x : gu[i].y) & 0xFFFF0000u) : ((e < 2 ? gu[i].x : gu[i].y) << 16));
+          if (ACTK < 0 || GATE) x = (c0 + e < p.Cout) ? x : 0.f;      // sigmoid(0) != 0: keep the padded columns zero
+          v[e] = x;
+        }
+        union { bf16 b[4]; h_v2u u; } o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.b[e] = (bf16)v[e];
+        *reinterpret_cast<h_v2u*>(stage + (32 * i + r) * PITCH + (32 * j + 8 * g + 4 * h) * 2) = o.u;
+      }
+    }
+  }
+  // the wave's tile, row-major in LDS -> 16 bytes per lane, LPR lanes per row
+  constexpr int LPR = TN * 4, RPI = 64 / LPR;
+  const int lr = lane / LPR, lc = lane % LPR;
+  const int c = col0 + lc * 8;
+#pragma unroll
+  for (int it = 0; it < TM * 32 / RPI; ++it) {
+    const int row = it * RPI + lr, m = row0 + row;
+    const h_v4 d = *reinterpret_cast<const h_v4*>(stage + row * PITCH + lc * 16);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h_v4u, d), ry, (int)((m < p.M && c < climit) ? (unsigned)m * (unsigned)(p.ldy * 2) + (unsigned)c * 2u : OOB), 0, 0);
+  }
+}
+
 // UNITS = 32 / cb: (channel block, tap) units per 32-element slab. MODE 0 plain, 2 PReLU epilogue.
 // ONE_TAP: 1x1 kernels (GEMMs) - no tap masks, the K offset of a slab goes into the scalar offset of the buffer load.
 template <int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
-__global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM * 32 % 64 == 0 && WGN * TN * 32 % 64 == 0 ? 3 : 2) : 3))) void conv_bf16_kernel(ConvParamsH p, const int ntiles) {
+__global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM * 32 % 64 == 0 && WGN * TN * 32 % 64 == 0 ? 3 : 2) : 3))) void conv_bf16_kernel(ConvParamsH p, const int ntiles, const int ntotal) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int AI = (BM + 63) / 64, BI = (BN + 63) / 64;    // DMA pieces per wave per slab (16 rows x 64 B each)
   constexpr int SLAB = (BM + BN) * 64;                       // bytes per slab
@@ -58,56 +164,61 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
     p.y += bo * p.ys2 + bi * p.ys1;
     if (p.shift) p.shift += bi * p.hs1;
   }
-  const int bid = blockIdx.x, nwg = gridDim.x;
-  const int q8 = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
-  const int swz = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
-  const int mt = swz / ntiles, nt = swz - mt * ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
   const int r = lane & 31, h = lane >> 5;
 
-  // ---- DMA source coordinates (per lane, fixed for the whole K loop) -------------------------------------
+  // ---- DMA source coordinates (per lane, fixed for the K loop of one tile) -------------------------------
   const int rsub = lane >> 2, slot = lane & 3;
   const int chunk = slot ^ ((rsub >> 2) & 3);            // source chunk (8 elements) of the slab after the swizzle
   const int upar = UNITS == 2 ? (chunk >> 1) : 0;        // which unit of the slab this lane's chunk belongs to
   const int cofs = UNITS == 2 ? (chunk & 1) * 8 : chunk * 8;   // element offset of the chunk inside its unit
-  unsigned aoffs[AI];          // byte offset of the row's (kh=0,kw=0,ci=cofs) element from p.x (buffer addressing)
-  unsigned long long amask[AI];
   const int HoWo = p.Ho * p.Wo;
   const int ntaps = p.KH * p.KW;
-#pragma unroll
-  for (int j = 0; j < AI; ++j) {
-    const int row = 16 * (4 * j + wave) + rsub;
-    const int m = m0 + row;
-    const bool valid = (row < BM) && (m < p.M);
-    const int mm = valid ? m : 0;
-    const int nimg = mm / HoWo;
-    const int rem = mm - nimg * HoWo;
-    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-    const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
-    const long long pix = ((long long)nimg * p.H + ih0) * p.W + iw0;
-    aoffs[j] = (unsigned)((pix * p.ldx + cofs) * 2);
-    unsigned long long mk = 0;
-    if (valid) {
-      for (int tp = 0; tp < ntaps; ++tp) {
-        const int kh = tp / p.KW, kw = tp - kh * p.KW;
-        const int ih = ih0 + kh * p.dh, iw = iw0 + kw * p.dw;
-        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) mk |= 1ull << tp;
-      }
-    }
-    amask[j] = mk;
-  }
+  int m0 = 0, n0 = 0;
+  unsigned aoffs[AI];          // byte offset of the row's (kh=0,kw=0,ci=cofs) element from p.x (buffer addressing)
+  unsigned long long amask[AI];
   unsigned boffs[BI];
+  // tile v of the launch's ntotal = mtiles * ntiles: XCD-aware bijection (workgroup ids go round-robin over the 8 XCDs, each XCD gets a
+  // contiguous run of tiles, n fastest, so the tiles sharing an A row block meet in one L2). The persistent wide tiles walk
+  // v = blockIdx.x, + gridDim.x, ... (gridDim.x % 8 == 0 whenever a workgroup takes more than one tile: it stays on its XCD's run).
+  auto setup_tile = [&](const int v) __attribute__((always_inline)) {
+    const int q8 = ntotal >> 3, rr = ntotal & 7, xcd = v & 7;
+    const int swz = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (v >> 3);
+    const int mt = swz / ntiles, nt = swz - mt * ntiles;
+    m0 = mt * BM; n0 = nt * BN;
 #pragma unroll
-  for (int j = 0; j < BI; ++j) {
-    const int row = 16 * (4 * j + wave) + rsub;
-    int n = n0 + row;
-    if (n > p.Cout - 1) n = p.Cout - 1;   // columns past Cout are computed on a valid row and discarded
-    boffs[j] = (unsigned)(((size_t)n * p.ldw + chunk * 8) * 2);
-  }
+    for (int j = 0; j < AI; ++j) {
+      const int row = 16 * (4 * j + wave) + rsub;
+      const int m = m0 + row;
+      const bool valid = (row < BM) && (m < p.M);
+      const int mm = valid ? m : 0;
+      const int nimg = mm / HoWo;
+      const int rem = mm - nimg * HoWo;
+      const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+      const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
+      const long long pix = ((long long)nimg * p.H + ih0) * p.W + iw0;
+      aoffs[j] = (unsigned)((pix * p.ldx + cofs) * 2);
+      unsigned long long mk = 0;
+      if (valid) {
+        for (int tp = 0; tp < ntaps; ++tp) {
+          const int kh = tp / p.KW, kw = tp - kh * p.KW;
+          const int ih = ih0 + kh * p.dh, iw = iw0 + kw * p.dw;
+          if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) mk |= 1ull << tp;
+        }
+      }
+      amask[j] = mk;
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+      const int row = 16 * (4 * j + wave) + rsub;
+      int n = n0 + row;
+      if (n > p.Cout - 1) n = p.Cout - 1;   // columns past Cout are computed on a valid row and discarded
+      boffs[j] = (unsigned)(((size_t)n * p.ldw + chunk * 8) * 2);
+    }
+  };
+  setup_tile(blockIdx.x);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.x), 0, (int)p.x_span, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.w), 0, (int)p.w_span, 0x00020000);
 
@@ -115,11 +226,16 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
   const int CB = 32 / UNITS;
   int tap0 = 0, kh0 = 0, kw0 = 0, ci0 = 0;                       // unit 0 of the next slab
   int tap1 = 0, kh1 = 0, kw1 = 0, ci1 = 0;                       // unit 1 (UNITS == 2)
-  if (UNITS == 2) {
-    tap1 = 1; kw1 = 1;
-    if (kw1 == p.KW) { kw1 = 0; kh1 = 1; }
-    if (tap1 == ntaps) { tap1 = 0; kh1 = 0; kw1 = 0; ci1 = CB; }
-  }
+  auto reset_units = [&]() __attribute__((always_inline)) {                                     // K position 0 (start of a tile)
+    tap0 = kh0 = kw0 = ci0 = 0;
+    tap1 = kh1 = kw1 = ci1 = 0;
+    if (UNITS == 2) {
+      tap1 = 1; kw1 = 1;
+      if (kw1 == p.KW) { kw1 = 0; kh1 = 1; }
+      if (tap1 == ntaps) { tap1 = 0; kh1 = 0; kw1 = 0; ci1 = CB; }
+    }
+  };
+  reset_units();
   auto advance = [&](int& tap, int& kh, int& kw, int& ci) {      // + UNITS units
 #pragma unroll
     for (int s = 0; s < UNITS; ++s) {
@@ -176,12 +292,15 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
   };
 
   h_f32x16 acc[TM][TN];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  };
+  zero_acc();
 
   // fragment read offsets (bytes): row*64 + ((2s+h) ^ sw)*16, sw = (row>>2)&3 = (r>>2)&3; s = which 16-deep MFMA of the slab
   const int sw = (r >> 2) & 3;
@@ -233,7 +352,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
       const int hh = q_ / (TM * TN), i = (q_ / TN) % TM, j = q_ % TN;                                                \
       H8 a_, b_;                                                                                                     \
       a_.f = fa[SET][2 * i + hh]; b_.f = fb[SET][2 * j + hh];                                                        \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i][j], 0, 0, 0);                           \
+      if constexpr (TN > 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_.b, a_.b, acc[i][j], 0, 0, 0);   /* transposed tile */ \
+      else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i][j], 0, 0, 0);                      \
       _Pragma("unroll") for (int n_ = 0; n_ < NP_; ++n_)                                                             \
         if (((n_ + 1) * Q_ / (NP_ + 1) - 1 < 0 ? 0 : (n_ + 1) * Q_ / (NP_ + 1) - 1) == q_) {                         \
           __builtin_amdgcn_sched_barrier(0);                                                                         \
@@ -270,7 +390,26 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
   // so every LDS read is `base + immediate` and every DMA destination `base + immediate`; the counted wait is an immediate; the last
   // three slabs still "issue" their pieces, with out-of-range offsets (zero fill, no memory traffic), so every iteration is the
   // same straight-line code; 1x1 kernels pass the slab's K offset as the scalar offset of the load (no VALU at all per piece).
+  // wide wave tiles: the register-resident epilogue on the transposed accumulators, specialised on the common activation / residual forms
+  auto wide_epilogue = [&](const int row0, const int col0) __attribute__((always_inline)) {
+    if constexpr (TN > 1) {
+      char* const stage = smem_h + wave * (TM * 32) * (TN * 64 + 16);       // wave-private image of its TM*32 x TN*32 tile
+      const bool plain = !p.gate && !(p.res && p.res_after_act);
+      if (plain && p.act == ACT_NONE) {
+        if (p.res) h_epilogue_wide<TM, TN, 0, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 0, false, false>(acc, p, row0, col0, lane, stage);
+      } else if (plain && p.act == ACT_RELU) {
+        if (p.res) h_epilogue_wide<TM, TN, 1, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 1, false, false>(acc, p, row0, col0, lane, stage);
+      } else if (plain && p.act == ACT_GELU) {
+        if (p.res) h_epilogue_wide<TM, TN, 2, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 2, false, false>(acc, p, row0, col0, lane, stage);
+      } else if (p.gate) {
+        if (p.res) h_epilogue_wide<TM, TN, -1, true, true>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, -1, false, true>(acc, p, row0, col0, lane, stage);
+      } else {
+        if (p.res) h_epilogue_wide<TM, TN, -1, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, -1, false, false>(acc, p, row0, col0, lane, stage);
+      }
+    }
+  };
   constexpr bool LEAN = (BM % 64 == 0) && (BN % 64 == 0);
+  static_assert(TN == 1 || (LEAN && MODE == 0), "wide tiles: lean loop, no PReLU epilogue");
   // 64x64 wave tiles keep ONE fragment set (read after the MFMAs of the slab before, exposed LDS latency covered by the other waves):
   // 32 VGPRs fewer = three workgroups per CU instead of two, i.e. 144 KB instead of 96 KB of the 160 KB LDS holding DMA data in flight
   constexpr bool DBUF = (TM * TN < 4);
@@ -309,7 +448,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
       const bool live_ = g3 < nsub;                                                                                     \
       if constexpr ((Q) < AI) {                                                                                         \
         if constexpr (ONE_TAP) {                                                                                        \
-          const unsigned off_ = live_ ? aoffs_l[(Q) < AI ? (Q) : 0] : 0xFFFFFFF0u;                                      \
+          const unsigned off_ = live_ ? aoffs_l[(Q) < AI ? (Q) : 0] : 0xFFFFFFF0u;                      \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 4096 * (Q)), 16, (int)off_, g3 * 64, 0, 0);   \
         } else {                                                                                                        \
           const bool ok_ = ((amask[(Q) < AI ? (Q) : 0] >> l_tap) & 1ull) && l_cok && live_;                              \
@@ -317,7 +456,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 4096 * (Q)), 16, (int)off_, 0, 0, 0);         \
         }                                                                                                               \
       } else {                                                                                                          \
-        const unsigned off_ = live_ ? boffs[(Q) >= AI ? (Q) - AI : 0] : 0xFFFFFFF0u;                                    \
+        const unsigned off_ = live_ ? boffs[(Q) >= AI ? (Q) - AI : 0] : 0xFFFFFFF0u;                    \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(dB + (SLOT) * SLAB + 4096 * ((Q) - AI)), 16, (int)off_, g3 * 64, 0, 0); \
       }                                                                                                                 \
     }
@@ -336,7 +475,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
       constexpr int hh_ = (Q) / (TM * TN), i_ = ((Q) / TN) % TM, j_ = (Q) % TN;                                         \
       H8 a_, b_;                                                                                                        \
       a_.f = fa[SET][2 * i_ + hh_]; b_.f = fb[SET][2 * j_ + hh_];                                                       \
-      acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i_][j_], 0, 0, 0);                          \
+      if constexpr (TN > 1) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_.b, a_.b, acc[i_][j_], 0, 0, 0);  /* transposed tile */ \
+      else acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i_][j_], 0, 0, 0);                     \
     }
 #define FL_PIECE_AT(SLOT, N, Q)                                                                                          \
     if constexpr ((N) < NPW && (((N) + 1) * (2 * TM * TN) / (NPW + 1) - 1 < 0 ? 0 : ((N) + 1) * (2 * TM * TN) / (NPW + 1) - 1) == (Q)) { \
@@ -420,6 +560,10 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
 #undef FH_MFMA_BURST_ISSUE
 #undef FH_READ_FRAGS
   __syncthreads();   // all fragment reads retired before the epilogue reuses the ring as staging
+  if constexpr (TN > 1) {
+    wide_epilogue(m0 + wm * TM * 32, n0 + wn * TN * 32);
+    return;
+  }
 
   // Two epilogue forms (as in kernels_conv_dma.hip). Narrow wave tiles (TN = 1: the tiles of the HBM-bound short-K layers) keep the
   // fully unrolled row code with every residual row requested up front (K = 64 -> 256 expand: 4.2 vs 3.8 TB/s against the rolled
@@ -550,135 +694,6 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
     }
   
     return;
-  } else {
-  // ---- epilogue: transpose through a wave-private LDS region; each lane then owns 8 consecutive channels of a row -----------
-    // Code size matters here: the activation chain (erf, exp, log1p) inlined into a fully unrolled epilogue came to ~37k instructions
-    // per kernel, more than the instruction cache holds, and cost the 128x128 tile ~25 us per workgroup. So only the accumulator ->
-    // LDS writes are unrolled (register indices); the read-back / scale / residual / activation / gate / store part is ONE rolled loop
-    // over the lane's rows with the next row's residual and gate requested an iteration ahead; 16-byte accesses when legal
-    // (p.vec_epi), per-element ones otherwise.
-    float* smem = reinterpret_cast<float*>(smem_h);
-    constexpr int WC = TN * 32, ES = WC + 4, LPR = WC / 8, RPI = 64 / LPR, NIT = 32 / RPI;
-    float* E = smem + wave * 32 * ES;
-    const int lr = lane / LPR, lc = (lane % LPR) * 8;
-    const int colb = n0 + wn * WC + lc;
-    const bool vec = p.vec_epi != 0;
-    const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
-    const bool cok = colb < climit;                        // the lane has at least one column to store
-    const bool cfull = colb + 8 <= p.Cout;
-    float sc[8], sf[8], sl[8];
-  #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool cv = colb + e < p.Cout;
-      sc[e] = (cv && p.scale) ? p.scale[colb + e] : 1.f;
-      sf[e] = (cv && p.shift) ? p.shift[colb + e] : 0.f;
-      sl[e] = (MODE == 2 && cv) ? p.slope[colb + e] : 0.f;
-    }
-    const int act = p.act;
-    // 8 channels of one row of a bf16 tensor as one packed 16-byte value: one vector load, or per-element loads (zeros past Cout)
-    auto load8 = [&](const bf16* base, size_t row_off) -> uint4 {
-      if (vec && cfull) return *reinterpret_cast<const uint4*>(base + row_off + colb);
-      const unsigned short* b16 = reinterpret_cast<const unsigned short*>(base) + row_off + colb;
-      unsigned w[8];
-  #pragma unroll
-      for (int e = 0; e < 8; ++e) w[e] = (colb + e < p.Cout) ? (unsigned)b16[e] : 0u;
-      return make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16));
-    };
-    auto row_of = [&](int i, int it) { return m0 + wm * TM * 32 + i * 32 + lr + it * RPI; };
-    auto fetch_res = [&](int m) -> uint4 {
-      const int mc = m < p.M ? m : p.M - 1;
-      return p.res ? load8(p.res, (size_t)mc * p.ldr) : make_uint4(0, 0, 0, 0);
-    };
-    auto fetch_gate = [&](int m) -> uint4 {      // gate_c1: the single channel's value in .x (as float bits)
-      const int mc = m < p.M ? m : p.M - 1;
-      if (!p.gate) return make_uint4(0, 0, 0, 0);
-      if (p.gate_c1) return make_uint4(__float_as_uint((float)p.gate[(size_t)mc * p.ldg]), 0, 0, 0);
-      return load8(p.gate, (size_t)mc * p.ldg);
-    };
-    // one row of the lane: E -> scale / shift / residual / activation / gate -> store
-    auto finish_row = [&](int m, int erow, const uint4 ru, const uint4 gu) {
-      const float4 v0 = *reinterpret_cast<const float4*>(&E[erow * ES + lc]);
-      const float4 v1 = *reinterpret_cast<const float4*>(&E[erow * ES + lc + 4]);
-      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      float rf[8], gf[8];
-      if (p.res) h_unpack8(ru, rf);
-      if (p.gate && !p.gate_c1) h_unpack8(gu, gf);
-      const float gs = __uint_as_float(gu.x);
-  #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = v[e] * sc[e] + sf[e];
-        if (p.res && !p.res_after_act) x += rf[e];
-        v[e] = x;
-      }
-      // one activation branch per row (block-uniform), not per element
-      if constexpr (MODE == 2) {
-  #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * sl[e];
-      } else if (act == ACT_RELU) {
-  #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-      } else if (act == ACT_GELU) {
-  #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + fe_erf_fast(v[e] * 0.70710678118654752440f));
-      } else if (act == ACT_SIGMOID) {
-  #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = __frcp_rn(1.f + __expf(-v[e]));
-      } else if (act == ACT_SOFTPLUS) {
-  #pragma unroll 1
-        for (int e = 0; e < 8; ++e) v[e] = v[e] > 20.f ? v[e] : log1pf(expf(v[e]));
-      }
-  #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = v[e];
-        if (p.res && p.res_after_act) x += rf[e];
-        if (p.gate) x *= p.gate_c1 ? gs : gf[e];
-        if (colb + e >= p.Cout) x = 0.f;                 // pad_store: the ragged tail of the last group is written as zeros
-        v[e] = x;
-      }
-      if (cok && m < p.M) {
-        bf16* yp = p.y + (size_t)m * p.ldy + colb;
-        if (vec) {
-          H8 o;
-  #pragma unroll
-          for (int e = 0; e < 8; ++e) o.b[e] = (bf16)v[e];
-          *reinterpret_cast<uint4*>(yp) = o.u;
-        } else {
-  #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (colb + e < p.Cout) yp[e] = (bf16)v[e];
-        }
-      }
-    };
-    // Narrow wave tiles (TN = 1: two rows per lane and 32-row slab; the tiles of the HBM-bound short-K layers) request the residual /
-    // gate rows of ALL their slabs before the first transpose - twice the bytes in flight; their row loop is short enough to unroll.
-    constexpr bool AHEAD = (TN == 1);
-    uint4 rall[AHEAD ? TM * NIT : 1];      // the gate (one layer type of the TOPIQ head) is fetched per row, just in time
-    if constexpr (AHEAD) {
-  #pragma unroll
-      for (int i = 0; i < TM; ++i)
-  #pragma unroll
-        for (int it = 0; it < NIT; ++it) rall[i * NIT + it] = fetch_res(row_of(i, it));
-    }
-  #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-  #pragma unroll
-      for (int j = 0; j < TN; ++j)
-  #pragma unroll
-        for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
-      if constexpr (AHEAD) {
-  #pragma unroll
-        for (int it = 0; it < NIT; ++it) finish_row(row_of(i, it), lr + it * RPI, rall[i * NIT + it], fetch_gate(row_of(i, it)));
-      } else {
-        uint4 rn = fetch_res(row_of(i, 0)), gn = fetch_gate(row_of(i, 0));
-  #pragma unroll 1
-        for (int it = 0; it < NIT; ++it) {
-          const uint4 ru = rn, gu = gn;
-          if (it + 1 < NIT) { rn = fetch_res(row_of(i, it + 1)); gn = fetch_gate(row_of(i, it + 1)); }
-          finish_row(row_of(i, it), lr + it * RPI, ru, gu);
-        }
-      }
-    }
-  
   }
 }
 
@@ -687,12 +702,15 @@ static void launch_bf16_variant(const ConvParamsH& p, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
   constexpr size_t main_lds = (size_t)3 * (BM + BN) * 64;
-  constexpr size_t epi_lds = (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
+  constexpr size_t epi_lds = TN > 1 ? (size_t)4 * (TM * 32) * (TN * 64 + 16)      // wide tiles: bf16 image of every wave's tile
+                                    : (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   auto kern = conv_bf16_kernel<WGM, WGN, TM, TN, UNITS, MODE, ONE_TAP>;
   static std::atomic<uint64_t> lds_set{0};
   ensure_dynamic_lds((const void*)kern, lds, lds_set);
-  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, ntiles);
+  const int ntotal = mtiles * ntiles;
+  int gx = ntotal;
+  hipLaunchKernelGGL(kern, dim3(gx, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, ntiles, ntotal);
   FE_HIP(hipGetLastError());
 }
 
@@ -778,6 +796,14 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
   // measured 733 vs 1028 images/s on TOPIQ - occupancy beats barrier count here
   static const int force_tile = getenv("FE_BF16_TILE") ? atoi(getenv("FE_BF16_TILE")) : 0;   // A/B hook
   if (force_tile && p.variant == 0 && p.Cout > 32) tile = force_tile;
+  // the wide tiles' epilogue (h_epilogue_wide) addresses y / res / gate through 32-bit buffer offsets in 8-byte quads
+  const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
+  const unsigned long long ysp = ((unsigned long long)(p.M - 1) * p.ldy + climit) * 2;
+  const unsigned long long rsp = p.res ? ((unsigned long long)(p.M - 1) * p.ldr + p.Cout) * 2 : 0;
+  const unsigned long long gsp = p.gate ? ((unsigned long long)(p.M - 1) * p.ldg + (p.gate_c1 ? 1 : p.Cout)) * 2 : 0;
+  const bool wide_ok = p.vec_epi && ysp < 0xFFFFFF00ull && rsp < 0xFFFFFF00ull && gsp < 0xFFFFFF00ull && (p.pad_store ? (!p.scale && !p.shift && !p.res && !p.gate) : true);
+  p.y_span = (unsigned)ysp; p.r_span = (unsigned)rsp; p.g_span = (unsigned)gsp;
+  if ((tile == 1 || tile == 8) && !wide_ok) tile = 7;
   const bool one_tap = ntaps == 1 && p.Cin % 64 == 0 && p.Kp == p.Cin;
   if (p.cb == 16) launch_bf16_tile<2>(p, tile, false, s);
   else launch_bf16_tile<1>(p, tile, one_tap, s);
