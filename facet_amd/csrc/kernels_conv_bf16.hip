@@ -51,7 +51,7 @@ __device__ __forceinline__ void h_unpack8(const uint4 u, float v[8]) {
 // store instruction would touch 32 rows with 16 bytes each, and the L2 takes a request per row segment, not per byte (measured on
 // the ViT-L/14 GEMMs: 8-byte register stores 642-790 TFLOP/s, the same kernels with the stores dropped 836-1000).
 // The transposing fp32 epilogue these tiles had before ran NIT dependent LDS round trips and residual fetches per 32 rows.
-// ACTK: 0 none, 1 ReLU, 2 GELU, -1 the activation named by p.act; GATE: multiplicative gate (TOPIQ GatedConv); the residual is added
+// ACTK: 0 none, 1 ReLU, 2 GELU, 3 sigmoid, -1 the activation named by p.act; GATE: multiplicative gate (TOPIQ GatedConv); the residual is added
 // before the activation unless p.res_after_act. launch_conv_bf16 picks a wide tile only where the 16-byte vector layout is legal
 // (p.vec_epi) and y / res / gate span less than 4 GB.
 typedef unsigned h_v2u __attribute__((ext_vector_type(2)));
@@ -121,10 +121,11 @@ __device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const C
           if (RES && !p.res_after_act) x += rf;
           if (ACTK == 1) x = x > 0.f ? x : 0.f;
           else if (ACTK == 2) x = 0.5f * x * (1.f + fe_erf_fast(x * 0.70710678118654752440f));
+          else if (ACTK == 3) x = __frcp_rn(1.f + __expf(-x));
           else if (ACTK < 0) x = fe_apply_act_fast(x, p.act);
           if (RES && p.res_after_act) x += rf;
           if (GATE) x *= __uint_as_float((e & 1) ? ((e < 2 ? gu[i].x : gu[i].y) & 0xFFFF0000u) : ((e < 2 ? gu[i].x : gu[i].y) << 16));
-          if (ACTK < 0 || GATE) x = (c0 + e < p.Cout) ? x : 0.f;      // sigmoid(0) != 0: keep the padded columns zero
+          if (ACTK < 0 || ACTK == 3) x = (c0 + e < p.Cout) ? x : 0.f;      // sigmoid(0) != 0: keep the padded columns zero
           v[e] = x;
         }
         union { bf16 b[4]; h_v2u u; } o;
@@ -394,6 +395,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
   auto wide_epilogue = [&](const int row0, const int col0) __attribute__((always_inline)) {
     if constexpr (TN > 1) {
       char* const stage = smem_h + wave * (TM * 32) * (TN * 64 + 16);       // wave-private image of its TM*32 x TN*32 tile
+      // straight-line forms of the combinations the models use; the rest (softplus gates, residual after the activation) take the
+      // form that reads activation, gate and residual order from the parameters
       const bool plain = !p.gate && !(p.res && p.res_after_act);
       if (plain && p.act == ACT_NONE) {
         if (p.res) h_epilogue_wide<TM, TN, 0, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 0, false, false>(acc, p, row0, col0, lane, stage);
@@ -401,6 +404,10 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
         if (p.res) h_epilogue_wide<TM, TN, 1, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 1, false, false>(acc, p, row0, col0, lane, stage);
       } else if (plain && p.act == ACT_GELU) {
         if (p.res) h_epilogue_wide<TM, TN, 2, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 2, false, false>(acc, p, row0, col0, lane, stage);
+      } else if (plain && p.act == ACT_SIGMOID && !p.res) {
+        h_epilogue_wide<TM, TN, 3, false, false>(acc, p, row0, col0, lane, stage);
+      } else if (p.gate && !p.res && p.act == ACT_GELU) {
+        h_epilogue_wide<TM, TN, 2, false, true>(acc, p, row0, col0, lane, stage);       // TOPIQ GatedConv, default gate activation
       } else if (p.gate) {
         if (p.res) h_epilogue_wide<TM, TN, -1, true, true>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, -1, false, true>(acc, p, row0, col0, lane, stage);
       } else {
