@@ -783,9 +783,11 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
     // relative efficiencies measured on the ViT / ResNet shapes (FE_BF16_TILE sweeps, profiles/r02_README.md): long K loops want the
     // 256x128 tile (847 vs 693 vs 535 TFLOP/s at K = 4096), K = 1024 still prefers the large tiles (655-670 / 645 / 535), short K is
     // bound by its output streams and wants the four workgroups per CU of the 128x64 tile
-    const double e8 = p.K >= 2048 ? 1.00 : (p.K >= 512 ? 1.00 : 0.70);
-    const double e1 = p.K >= 2048 ? 0.82 : (p.K >= 512 ? 0.97 : 0.80);
-    const double e7 = p.K >= 2048 ? 0.63 : (p.K >= 512 ? 0.81 : 1.00);
+    // K = 256 (FE_BF16_TILE sweep of TOPIQ after the wide tiles got their coalesced epilogue): 128x128 wins the small-M layers by
+    // 8-13 %, 256x128 the large-M ones by 20-30 %, 128x64 keeps K = 64 / 128
+    const double e8 = p.K >= 2048 ? 1.00 : (p.K >= 512 ? 1.00 : 0.97);
+    const double e1 = p.K >= 2048 ? 0.82 : (p.K >= 512 ? 0.97 : 1.00);
+    const double e7 = p.K >= 2048 ? 0.63 : (p.K >= 512 ? 0.81 : 0.88);
     const Cand wide[4] = {{8, 256, 128, e8}, {1, 128, 128, e1}, {7, 128, 64, e7}, {4, 64, 64, 0.7 * e7}};
     static const Cand narrow[2] = {{7, 128, 64, 1.00}, {4, 64, 64, 0.90}};
     static const Cand slim[2] = {{3, 256, 32, 1.00}, {5, 128, 32, 0.92}};
@@ -793,7 +795,7 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
     const int nc = p.Cout > 64 ? 4 : 2;
     double best = 1e300;
     for (int i = 0; i < nc; ++i) {
-      if (p.Cout > 64 && p.K <= 256 && (cs[i].tile == 1 || cs[i].tile == 8)) continue;   // short K: 128x64 (four workgroups per CU)
+      if (p.Cout > 64 && p.K < 256 && (cs[i].tile == 1 || cs[i].tile == 8)) continue;   // short K: 128x64 (four workgroups per CU)
       const long long wgs = (long long)((p.M + cs[i].bm - 1) / cs[i].bm) * ((p.Cout + cs[i].bn - 1) / cs[i].bn) * p.batch;
       const double cost = (double)((wgs + 255) / 256) * cs[i].bm * cs[i].bn / cs[i].eff;
       if (cost < best) { best = cost; tile = cs[i].tile; }
