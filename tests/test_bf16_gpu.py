@@ -45,6 +45,15 @@ CASES = [
     (1, 64, 12, 12, 20, 3, 1, 1, 1, "sigmoid", False),    # Cout % 8 != 0: scalar epilogue
     (1, 512, 7, 7, 1024, 1, 1, 0, 1, None, False),        # wide N, small M
     (3, 64, 28, 28, 64, 3, 1, 1, 1, "softplus", False),
+    # wide wave tiles (K >= 256, Cout > 64: transposed accumulators, register epilogue, LDS-staged 16-byte stores), every epilogue form
+    (2, 256, 17, 19, 192, 1, 1, 0, 1, None, False),       # ragged M (646 rows), Cout = 1.5 tile columns
+    (2, 256, 17, 19, 256, 1, 1, 0, 1, "relu", True),      # residual before the activation
+    (1, 512, 23, 11, 384, 1, 1, 0, 1, "gelu", False),
+    (1, 1024, 16, 20, 128, 1, 1, 0, 1, None, True),       # long K, residual, no activation (ViT projection form)
+    (1, 256, 14, 14, 512, 1, 1, 0, 1, "sigmoid", False),
+    (1, 256, 14, 14, 136, 1, 1, 0, 1, "softplus", True),  # parameter-driven form; Cout % 8 == 0 but not a multiple of 32
+    (1, 256, 20, 20, 256, 3, 1, 1, 1, "relu", False),     # 3x3, K = 2304
+    (5, 320, 32, 32, 256, 1, 1, 0, 1, "gelu", True),      # 5120 rows: 256-row tiles, several per column
 ]
 
 
@@ -73,7 +82,7 @@ def test_bf16_integer_data_is_exact(eng16):
     """Small integers are exact in bf16 and their sums exact in fp32: any indexing mistake (tap order, channel blocks, swizzle,
     fragment maps) shows up as a wrong integer, not as 'noise'. Asymmetric weights, non-square image, both channel-block sizes."""
     rng = np.random.default_rng(5)
-    for cin, cout in ((32, 40), (16, 8), (96, 64)):
+    for cin, cout in ((32, 40), (16, 8), (96, 64), (64, 192)):       # the last one: K = 576 on the wide tiles
         x = rng.integers(-1, 2, (2, cin, 11, 14)).astype(np.float32)
         w = rng.integers(-1, 2, (cout, cin, 3, 3)).astype(np.float32)
         ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1).numpy()
