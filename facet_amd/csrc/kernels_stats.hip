@@ -18,7 +18,7 @@ enum { ST_HIST = 0, ST_LAP_SUM = 256, ST_LAP_SUMSQ = 257, ST_NOISE_ABS = 258, ST
 struct StatsAccum {            // device accumulators per image
   unsigned int hist[256];
   long long lap_sum, lap_sumsq, noise_abs, sat_sum;
-  double hs_clog2c;
+  double hs_clog2c[2];         // one term per half of the hue range (block of pass 1), each summed in a fixed order
 };
 
 __device__ __forceinline__ int gray_of(int b, int g, int r) { return (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15; }
@@ -119,7 +119,17 @@ __global__ __launch_bounds__(1024) void stats_pass1_kernel(const uint8_t* __rest
     if (c) part += (double)c * log2((double)c);
   }
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-  if ((threadIdx.x & 63) == 0 && part != 0.0) atomicAdd(&acc[img].hs_clog2c, part);
+  // the wave terms are added in wave order by one thread: a floating-point atomic per wave made the last bit of the entropy depend on
+  // which wave came first (two runs of the same image could differ by one ulp)
+  double* wave_part = reinterpret_cast<double*>(sdiv_l);          // the division tables are dead after the pixel loop
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) tot += wave_part[wv];
+    acc[img].hs_clog2c[half] = tot;
+  }
   for (int o = 32; o > 0; o >>= 1) sat += __shfl_xor(sat, o);
   if ((threadIdx.x & 63) == 0 && sat) atomicAdd((unsigned long long*)&acc[img].sat_sum, (unsigned long long)sat);
   for (int i = threadIdx.x; i < 256; i += blockDim.x)
@@ -168,7 +178,7 @@ __global__ void stats_pack_kernel(const StatsAccum* __restrict__ acc, int n, dou
     o[ST_LAP_SUMSQ] = (double)acc[img].lap_sumsq;
     o[ST_NOISE_ABS] = (double)acc[img].noise_abs;
     o[ST_SAT_SUM] = (double)acc[img].sat_sum;
-    o[ST_HS_CLOG2C] = acc[img].hs_clog2c;
+    o[ST_HS_CLOG2C] = acc[img].hs_clog2c[0] + acc[img].hs_clog2c[1];
     o[261] = o[262] = o[263] = 0.0;
   }
 }
