@@ -1,725 +1,7 @@
-// Implicit-GEMM convolution / GEMM on the bf16 matrix cores of gfx950 (v_mfma_f32_32x32x16_bf16, fp32 accumulate): the contraction
-// kernel of the reduced-precision path (BASELINE.json configs[3]: TOPIQ + SAMP-Net + CLIP ViT-L/14 in bf16; the reference itself runs
-// CLIP in half precision on a GPU, processing/scorer.py:513-516). bf16 NHWC activations and bf16 packed weights in HBM, fp32
-// accumulators, fp32 per-channel scale / shift (folded BatchNorm, bias), fp32 activation math, one rounding to bf16 at the store.
-//
-//   Y[m][co] = act( (sum_k A[m][k] * Wt[co][k]) * scale[co] + shift[co] (+ res[m][co]) ) (* gate[m])
-//
-// Structure = conv_dma_kernel's (kernels_conv_dma.hip), re-cut for 2-byte elements:
-//   * a K "slab" is 32 bf16 = 64 B per row, moved HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB = 16 rows per wave
-//     instruction); lane-linear LDS image with the XOR swizzle applied on the SOURCE side and mirrored in the ds_read_b128 address;
-//   * one ds_read_b128 = 8 bf16 = a lane's whole A (or B) fragment of one 32x32x16 MFMA (lane (r, h): k = 8h .. 8h+7): 2 MFMAs per
-//     32x32 tile and slab; the slab's DMA pieces for three slabs ahead are issued between those MFMAs;
-//   * 3-slab LDS ring, counted vmcnt, one raw s_barrier per slab, register double-buffered fragments (inline-asm ds_read so hipcc
-//     does not drain the DMA ring in front of every LDS read);
-//   * K order of the packed weights / the implicit im2col: channel block (cb = 32, or 16 when Cin % 32 != 0) outer, tap inner,
-//     channel-in-block innermost. With cb = 16 a slab holds TWO (block, tap) units: lanes pick theirs by the half of the slab
-//     their 16-B chunk lies in. 1x1 kernels (GEMMs) take any Cin % 8 == 0: the chunk past Cin is fetched as zeros;
-//   * padding taps / rows past M / chunks past Cin = out-of-range buffer offsets (the hardware returns zeros);
-//   * epilogue: narrow wave tiles (TN = 1) through a wave-private LDS transpose to 16-byte (8 x bf16) row stores; wide wave tiles
-//     (TN = 2) swap the MFMA operands so the accumulators come out transposed and finish in registers (h_epilogue_wide).
-#include "fe_common.h"
-#include <cstdlib>
+// bf16 implicit-GEMM convolution: tile policy, launcher and the narrow-tile instantiations (kernel: conv_bf16_kernel.h).
+#include "conv_bf16_kernel.h"
 
 namespace fe {
-
-typedef float h_f32x16 __attribute__((ext_vector_type(16)));
-typedef float h_v4f __attribute__((ext_vector_type(4)));
-typedef __bf16 h_bf8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) void* h_lptr_t;
-
-union H8 {            // 16 bytes: one DMA chunk / one MFMA fragment / one epilogue store
-  h_v4f f;
-  h_bf8 b;
-  uint4 u;
-};
-
-__device__ __forceinline__ void h_unpack8(const uint4 u, float v[8]) {
-  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
-  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
-  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xFFFF0000u);
-  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xFFFF0000u);
-}
-
-
-// Epilogue of the wide wave tiles (TN >= 2). Their MFMAs take the operands SWAPPED (weights as the row operand): the accumulator of a
-// 32x32 tile then holds, in lane (r, h), pixel row r and the channels 8g + 4h + {0..3} (g = 0..3) - four CONSECUTIVE channels per
-// register quad. Scale / shift / residual / activation / the rounding to bf16 all run on the registers, straight-line: every global
-// access is a buffer load whose offset is pushed out of range for rows past M and columns past Cout (reads return zeros), so the
-// math is ONE basic block and the compiler hoists its loads. The packed quads (8 bytes) then go through a wave-private LDS image of
-// the wave tile, row-major, and leave as 16-byte stores, eight lanes per 128-byte row: written straight from the registers each
-// store instruction would touch 32 rows with 16 bytes each, and the L2 takes a request per row segment, not per byte (measured on
-// the ViT-L/14 GEMMs: 8-byte register stores 642-790 TFLOP/s, the same kernels with the stores dropped 836-1000).
-// The transposing fp32 epilogue these tiles had before ran NIT dependent LDS round trips and residual fetches per 32 rows.
-// ACTK: 0 none, 1 ReLU, 2 GELU, 3 sigmoid, -1 the activation named by p.act; GATE: multiplicative gate (TOPIQ GatedConv); the residual is added
-// before the activation unless p.res_after_act. launch_conv_bf16 picks a wide tile only where the 16-byte vector layout is legal
-// (p.vec_epi) and y / res / gate span less than 4 GB.
-typedef unsigned h_v2u __attribute__((ext_vector_type(2)));
-typedef unsigned h_v4u __attribute__((ext_vector_type(4)));
-typedef float h_v4 __attribute__((ext_vector_type(4)));
-template <int TM, int TN, int ACTK, bool RES, bool GATE>
-__device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const ConvParamsH& p, const int row0, const int col0,
-                                                const int lane, char* const stage) {
-  constexpr unsigned OOB = 0xFFFFFFF0u;
-  constexpr int PITCH = TN * 64 + 16;          // bytes per staged row: TN * 32 bf16 + 16 (conflict-free 8-byte writes, 16-byte aligned reads)
-  const int r = lane & 31, h = lane >> 5;
-  const int mb = row0 + r;                     // the lane's pixel row of tile row i: mb + 32 i
-  const int cb = col0 + 4 * h;                 // its first channel of tile column j, quad g: cb + 32 j + 8 g
-  const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
-  const bool hs = p.scale != nullptr, hb = p.shift != nullptr;
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_span, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(RES ? p.res : p.y), 0, RES ? (int)p.r_span : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(GATE ? p.gate : p.y), 0, GATE ? (int)p.g_span : 0, 0x00020000);
-  // a null scale / shift becomes an empty buffer: every read returns 0
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hs ? p.scale : p.shift), 0, hs ? p.Cout * 4 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb ? p.shift : p.scale), 0, hb ? p.Cout * 4 : 0, 0x00020000);
-  bool rok[TM];
-  unsigned rbo[TM], gbo[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = mb + 32 * i;
-    rok[i] = m < p.M;
-    rbo[i] = RES ? (unsigned)m * (unsigned)(p.ldr * 2) : 0u;
-    gbo[i] = GATE ? (unsigned)m * (unsigned)(p.ldg * 2) : 0u;
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    h_v4 sc[4], sf[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {      // Cout % 8 == 0 wherever a scale or shift exists (p.vec_epi): a quad is wholly inside or outside
-      const int c0 = cb + 32 * j + 8 * g;
-      const unsigned co = c0 < p.Cout ? (unsigned)c0 * 4u : OOB;
-      sc[g] = __builtin_bit_cast(h_v4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)co, 0, 0));
-      sf[g] = __builtin_bit_cast(h_v4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)co, 0, 0));
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c0 = cb + 32 * j + 8 * g;
-      h_v2u ru[TM], gu[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (RES) ru[i] = __builtin_amdgcn_raw_buffer_load_b64(rr, (int)((rok[i] && c0 < p.Cout) ? rbo[i] + (unsigned)c0 * 2u : OOB), 0, 0);
-        if (GATE) {
-          if (p.gate_c1) gu[i].x = gu[i].y = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rg, (int)(rok[i] ? gbo[i] : OOB), 0, 0) * 0x10001u;
-          else gu[i] = __builtin_amdgcn_raw_buffer_load_b64(rg, (int)((rok[i] && c0 < p.Cout) ? gbo[i] + (unsigned)c0 * 2u : OOB), 0, 0);
-        }
-      }
-      float s4[4], b4[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {        // no scale: 1 inside Cout, 0 past it (the zero columns of a pad_store row)
-        s4[e] = hs ? sc[g][e] : (c0 + e < p.Cout ? 1.f : 0.f);
-        b4[e] = sf[g][e];
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = acc[i][j][4 * g + e] * s4[e] + b4[e];
-          float rf = 0.f;
-          if (RES) rf = __uint_as_float((e & 1) ? ((e < 2 ? ru[i].x : ru[i].y) & 0xFFFF0000u) : ((e < 2 ? ru[i].x : ru[i].y) << 16));
-          if (RES && !p.res_after_act) x += rf;
-          if (ACTK == 1) x = x > 0.f ? x : 0.f;
-          else if (ACTK == 2) x = 0.5f * x * (1.f + fe_erf_fast(x * 0.70710678118654752440f));
-          else if (ACTK == 3) x = __frcp_rn(1.f + __expf(-x));
-          else if (ACTK < 0) x = fe_apply_act_fast(x, p.act);
-          if (RES && p.res_after_act) x += rf;
-          if (GATE) x *= __uint_as_float((e & 1) ? ((e < 2 ? gu[i].x : gu[i].y) & 0xFFFF0000u) : ((e < 2 ? gu[i].x : gu[i].y) << 16));
-          if (ACTK < 0 || ACTK == 3) x = (c0 + e < p.Cout) ? x : 0.f;      // sigmoid(0) != 0: keep the padded columns zero
-          v[e] = x;
-        }
-        union { bf16 b[4]; h_v2u u; } o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o.b[e] = (bf16)v[e];
-        *reinterpret_cast<h_v2u*>(stage + (32 * i + r) * PITCH + (32 * j + 8 * g + 4 * h) * 2) = o.u;
-      }
-    }
-  }
-  // the wave's tile, row-major in LDS -> 16 bytes per lane, LPR lanes per row
-  constexpr int LPR = TN * 4, RPI = 64 / LPR;
-  const int lr = lane / LPR, lc = lane % LPR;
-  const int c = col0 + lc * 8;
-#pragma unroll
-  for (int it = 0; it < TM * 32 / RPI; ++it) {
-    const int row = it * RPI + lr, m = row0 + row;
-    const h_v4 d = *reinterpret_cast<const h_v4*>(stage + row * PITCH + lc * 16);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h_v4u, d), ry, (int)((m < p.M && c < climit) ? (unsigned)m * (unsigned)(p.ldy * 2) + (unsigned)c * 2u : OOB), 0, 0);
-  }
-}
-
-// UNITS = 32 / cb: (channel block, tap) units per 32-element slab. MODE 0 plain, 2 PReLU epilogue.
-// ONE_TAP: 1x1 kernels (GEMMs) - no tap masks, the K offset of a slab goes into the scalar offset of the buffer load.
-template <int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
-__global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM * 32 % 64 == 0 && WGN * TN * 32 % 64 == 0 ? 3 : 2) : 3))) void conv_bf16_kernel(ConvParamsH p, const int ntiles, const int ntotal) {
-  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-  constexpr int AI = (BM + 63) / 64, BI = (BN + 63) / 64;    // DMA pieces per wave per slab (16 rows x 64 B each)
-  constexpr int SLAB = (BM + BN) * 64;                       // bytes per slab
-  constexpr int STEP = SLAB;                                 // bytes per ring entry (one slab per barrier: see launch_conv_bf16)
-  static_assert(WGM * WGN == 4, "4 waves");
-  extern __shared__ __attribute__((aligned(16))) char smem_h[];
-
-  if (p.batch > 1) {
-    const int b = blockIdx.y, bo = b / p.nb1, bi = b - bo * p.nb1;
-    p.x += bo * p.xs2 + bi * p.xs1;
-    p.w += bo * p.ws2 + bi * p.ws1;
-    p.y += bo * p.ys2 + bi * p.ys1;
-    if (p.shift) p.shift += bi * p.hs1;
-  }
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int r = lane & 31, h = lane >> 5;
-
-  // ---- DMA source coordinates (per lane, fixed for the K loop of one tile) -------------------------------
-  const int rsub = lane >> 2, slot = lane & 3;
-  const int chunk = slot ^ ((rsub >> 2) & 3);            // source chunk (8 elements) of the slab after the swizzle
-  const int upar = UNITS == 2 ? (chunk >> 1) : 0;        // which unit of the slab this lane's chunk belongs to
-  const int cofs = UNITS == 2 ? (chunk & 1) * 8 : chunk * 8;   // element offset of the chunk inside its unit
-  const int HoWo = p.Ho * p.Wo;
-  const int ntaps = p.KH * p.KW;
-  int m0 = 0, n0 = 0;
-  unsigned aoffs[AI];          // byte offset of the row's (kh=0,kw=0,ci=cofs) element from p.x (buffer addressing)
-  unsigned long long amask[AI];
-  unsigned boffs[BI];
-  // tile v of the launch's ntotal = mtiles * ntiles: XCD-aware bijection (workgroup ids go round-robin over the 8 XCDs, each XCD gets a
-  // contiguous run of tiles, n fastest, so the tiles sharing an A row block meet in one L2). The persistent wide tiles walk
-  // v = blockIdx.x, + gridDim.x, ... (gridDim.x % 8 == 0 whenever a workgroup takes more than one tile: it stays on its XCD's run).
-  auto setup_tile = [&](const int v) __attribute__((always_inline)) {
-    const int q8 = ntotal >> 3, rr = ntotal & 7, xcd = v & 7;
-    const int swz = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (v >> 3);
-    const int mt = swz / ntiles, nt = swz - mt * ntiles;
-    m0 = mt * BM; n0 = nt * BN;
-#pragma unroll
-    for (int j = 0; j < AI; ++j) {
-      const int row = 16 * (4 * j + wave) + rsub;
-      const int m = m0 + row;
-      const bool valid = (row < BM) && (m < p.M);
-      const int mm = valid ? m : 0;
-      const int nimg = mm / HoWo;
-      const int rem = mm - nimg * HoWo;
-      const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-      const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
-      const long long pix = ((long long)nimg * p.H + ih0) * p.W + iw0;
-      aoffs[j] = (unsigned)((pix * p.ldx + cofs) * 2);
-      unsigned long long mk = 0;
-      if (valid) {
-        for (int tp = 0; tp < ntaps; ++tp) {
-          const int kh = tp / p.KW, kw = tp - kh * p.KW;
-          const int ih = ih0 + kh * p.dh, iw = iw0 + kw * p.dw;
-          if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) mk |= 1ull << tp;
-        }
-      }
-      amask[j] = mk;
-    }
-#pragma unroll
-    for (int j = 0; j < BI; ++j) {
-      const int row = 16 * (4 * j + wave) + rsub;
-      int n = n0 + row;
-      if (n > p.Cout - 1) n = p.Cout - 1;   // columns past Cout are computed on a valid row and discarded
-      boffs[j] = (unsigned)(((size_t)n * p.ldw + chunk * 8) * 2);
-    }
-  };
-  setup_tile(blockIdx.x);
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.x), 0, (int)p.x_span, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.w), 0, (int)p.w_span, 0x00020000);
-
-  // block-uniform running state of the next unit(s) to fetch: unit u -> channel block u / ntaps, tap u % ntaps
-  const int CB = 32 / UNITS;
-  int tap0 = 0, kh0 = 0, kw0 = 0, ci0 = 0;                       // unit 0 of the next slab
-  int tap1 = 0, kh1 = 0, kw1 = 0, ci1 = 0;                       // unit 1 (UNITS == 2)
-  auto reset_units = [&]() __attribute__((always_inline)) {                                     // K position 0 (start of a tile)
-    tap0 = kh0 = kw0 = ci0 = 0;
-    tap1 = kh1 = kw1 = ci1 = 0;
-    if (UNITS == 2) {
-      tap1 = 1; kw1 = 1;
-      if (kw1 == p.KW) { kw1 = 0; kh1 = 1; }
-      if (tap1 == ntaps) { tap1 = 0; kh1 = 0; kw1 = 0; ci1 = CB; }
-    }
-  };
-  reset_units();
-  auto advance = [&](int& tap, int& kh, int& kw, int& ci) {      // + UNITS units
-#pragma unroll
-    for (int s = 0; s < UNITS; ++s) {
-      ++tap;
-      if (++kw == p.KW) { kw = 0; ++kh; }
-      if (tap == ntaps) { tap = 0; kh = 0; kw = 0; ci += CB; }
-    }
-  };
-  const int nsub = p.Kp / 32;            // slabs; Kp % 64 == 0
-  const int nsteps = nsub;
-
-  // One slab = AI A-pieces + BI B-pieces per wave. issue_begin fixes the slab's addresses, issue_piece(q) launches one 1-KiB LDS-DMA,
-  // issue_end advances the unit state: the main loop spreads the pieces BETWEEN the MFMAs of the current slab (a piece costs its wave
-  // 60-185 cycles of issue, an MFMA occupies the pipe for 32: issued in front of the burst the pieces took longer than the burst).
-  char* iAb = nullptr; char* iBb = nullptr;
-  int i_tb = 0, i_tap = 0, i_tbb = 0;
-  bool i_cok = true;
-  auto issue_begin = [&](int g) {
-    iAb = smem_h + (g % 3) * STEP;
-    iBb = iAb + BM * 64;
-    const int tb0 = ((kh0 * p.dh * p.W + kw0 * p.dw) * p.ldx + ci0) * 2;
-    int cil = ci0;
-    i_tb = tb0; i_tap = tap0;
-    if (UNITS == 2) {
-      const int tb1 = ((kh1 * p.dh * p.W + kw1 * p.dw) * p.ldx + ci1) * 2;
-      i_tb = upar ? tb1 : tb0; i_tap = upar ? tap1 : tap0; cil = upar ? ci1 : ci0;
-    }
-    i_cok = (cil + cofs) < p.Cin;   // chunk inside the channel range (the K tail and 1x1 kernels with Cin % 32 != 0)
-    i_tbb = g * 64;
-  };
-  auto issue_piece = [&](int q) {      // q < AI: A piece q; else B piece q - AI (q is a compile-time constant at every call site)
-    if (q < AI) {
-      const int j = q;
-      if (16 * (4 * j + wave) < BM) {
-        const bool ok = ((amask[j] >> i_tap) & 1ull) && i_cok;
-        const unsigned off = ok ? aoffs[j] + (unsigned)i_tb : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(iAb + 1024 * (4 * j + wave)), 16, (int)off, 0, 0, 0);
-      }
-    } else {
-      const int j = q - AI;
-      if (16 * (4 * j + wave) < BN)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(iBb + 1024 * (4 * j + wave)), 16, (int)boffs[j], i_tbb, 0, 0);
-    }
-  };
-  auto issue_end = [&]() {
-    advance(tap0, kh0, kw0, ci0);
-    if (UNITS == 2) advance(tap1, kh1, kw1, ci1);
-  };
-  auto issue_step = [&](int st) {      // whole slab at once (prologue)
-    issue_begin(st);
-#pragma unroll
-    for (int q = 0; q < AI + BI; ++q) issue_piece(q);
-    issue_end();
-  };
-
-  h_f32x16 acc[TM][TN];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  };
-  zero_acc();
-
-  // fragment read offsets (bytes): row*64 + ((2s+h) ^ sw)*16, sw = (row>>2)&3 = (r>>2)&3; s = which 16-deep MFMA of the slab
-  const int sw = (r >> 2) & 3;
-  const int fo0 = ((h ^ sw) << 4), fo1 = fo0 ^ 32;
-  const int aoff = (wm * TM * 32 + r) * 64, boff = BM * 64 + (wn * TN * 32 + r) * 64;
-
-  // pieces per wave per K-step (for the counted waits)
-  const int npw1 = (BM / 64) + ((16 * wave < BN) ? 1 : 0) + ((BN > 64 && 16 * (4 + wave) < BN) ? 1 : 0);
-  static_assert(BM % 64 == 0 && BN <= 128, "A pieces uniform over waves; B at most two pieces per wave");
-  const int npw = npw1;
-  auto wait_vm = [&](int n) {   // n is wave-uniform
-    switch (n) {
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-      case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-      case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-  };
-  const unsigned lds_base = (unsigned)(size_t)(h_lptr_t)smem_h;
-  h_v4f fa[2][2 * TM], fb[2][2 * TN];   // [register set][fragment]; indices are compile-time everywhere below
-#define FH_READ_FRAGS(SET, G)                                                                                        \
-  {                                                                                                                  \
-    const unsigned sb_ = lds_base + (unsigned)(((G) % 3) * STEP);                         \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                 \
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET][2 * i]) : "v"(sb_ + (unsigned)(aoff + i * 32 * 64 + fo0)));      \
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET][2 * i + 1]) : "v"(sb_ + (unsigned)(aoff + i * 32 * 64 + fo1)));  \
-    }                                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                 \
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET][2 * j]) : "v"(sb_ + (unsigned)(boff + j * 32 * 64 + fo0)));      \
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET][2 * j + 1]) : "v"(sb_ + (unsigned)(boff + j * 32 * 64 + fo1)));  \
-    }                                                                                                                \
-  }
-  // MFMA burst of one slab with this wave's DMA pieces of slab g+3 spread between the MFMAs (DO: block-uniform, false in the tail).
-  // Piece n goes behind MFMA max(0, (n + 1) * Q / (NP + 1) - 1); sched_barrier pins the order (hipcc otherwise gathers the loads in
-  // front of the MFMAs again).
-#define FH_MFMA_BURST_ISSUE(SET, DO)                                                                                 \
-  {                                                                                                                  \
-    constexpr int Q_ = 2 * TM * TN, NP_ = AI + BI;                                                                   \
-    _Pragma("unroll") for (int q_ = 0; q_ < Q_; ++q_) {                                                              \
-      const int hh = q_ / (TM * TN), i = (q_ / TN) % TM, j = q_ % TN;                                                \
-      H8 a_, b_;                                                                                                     \
-      a_.f = fa[SET][2 * i + hh]; b_.f = fb[SET][2 * j + hh];                                                        \
-      if constexpr (TN > 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_.b, a_.b, acc[i][j], 0, 0, 0);   /* transposed tile */ \
-      else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i][j], 0, 0, 0);                      \
-      _Pragma("unroll") for (int n_ = 0; n_ < NP_; ++n_)                                                             \
-        if (((n_ + 1) * Q_ / (NP_ + 1) - 1 < 0 ? 0 : (n_ + 1) * Q_ / (NP_ + 1) - 1) == q_) {                         \
-          __builtin_amdgcn_sched_barrier(0);                                                                         \
-          if (DO) issue_piece(n_);                                                                                   \
-          __builtin_amdgcn_sched_barrier(0);                                                                         \
-        }                                                                                                            \
-    }                                                                                                                \
-  }
-  // one slab: fragments of slab g are in register set CUR; slab g+1 is read into NXT under the MFMAs of g. Entering slab g+1 first
-  // waits for this wave's DMA pieces of it, then one barrier publishes it (and retires every wave's reads of slab g, whose buffer
-  // the pieces issued during this burst overwrite).
-#define FH_SLAB(CUR, NXT, G)                                                                                         \
-  {                                                                                                                  \
-    const int g_ = (G);                                                                                              \
-    bool do_issue_ = false;                                                                                          \
-    if (g_ + 1 < nsub) {                                                                                             \
-      wait_vm(g_ + 2 < nsub ? npw : 0);                                                                              \
-      __builtin_amdgcn_s_barrier();                                                                                  \
-      do_issue_ = g_ + 3 < nsub;                                                                                     \
-      if (do_issue_) issue_begin(g_ + 3);                                                                            \
-      FH_READ_FRAGS(NXT, g_ + 1)                                                                                     \
-    }                                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                               \
-    FH_MFMA_BURST_ISSUE(CUR, do_issue_)                                                                              \
-    if (do_issue_) issue_end();                                                                                      \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                               \
-  }
-
-  // Tiles whose waves all issue the same number of pieces (BM, BN multiples of 64) take the LEAN loop: the generic one spends ~125
-  // instructions per slab and wave (scalar branches around every piece, a switch for the counted wait, modulo-3 ring arithmetic, one
-  // VALU address per LDS read) on 4-8 MFMAs of 32 cycles - with four waves per SIMD the instruction issue, not the matrix pipe, set
-  // the pace (PMC: SQ_ACTIVE_INST_ANY 0.35 of the wave cycles). Lean form: unrolled by 6 = ring slot (mod 3) x register set (mod 2),
-  // so every LDS read is `base + immediate` and every DMA destination `base + immediate`; the counted wait is an immediate; the last
-  // three slabs still "issue" their pieces, with out-of-range offsets (zero fill, no memory traffic), so every iteration is the
-  // same straight-line code; 1x1 kernels pass the slab's K offset as the scalar offset of the load (no VALU at all per piece).
-  // wide wave tiles: the register-resident epilogue on the transposed accumulators, specialised on the common activation / residual forms
-  auto wide_epilogue = [&](const int row0, const int col0) __attribute__((always_inline)) {
-    if constexpr (TN > 1) {
-      char* const stage = smem_h + wave * (TM * 32) * (TN * 64 + 16);       // wave-private image of its TM*32 x TN*32 tile
-      // straight-line forms of the combinations the models use; the rest (softplus gates, residual after the activation) take the
-      // form that reads activation, gate and residual order from the parameters
-      const bool plain = !p.gate && !(p.res && p.res_after_act);
-      if (plain && p.act == ACT_NONE) {
-        if (p.res) h_epilogue_wide<TM, TN, 0, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 0, false, false>(acc, p, row0, col0, lane, stage);
-      } else if (plain && p.act == ACT_RELU) {
-        if (p.res) h_epilogue_wide<TM, TN, 1, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 1, false, false>(acc, p, row0, col0, lane, stage);
-      } else if (plain && p.act == ACT_GELU) {
-        if (p.res) h_epilogue_wide<TM, TN, 2, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 2, false, false>(acc, p, row0, col0, lane, stage);
-      } else if (plain && p.act == ACT_SIGMOID && !p.res) {
-        h_epilogue_wide<TM, TN, 3, false, false>(acc, p, row0, col0, lane, stage);
-      } else if (p.gate && !p.res && p.act == ACT_GELU) {
-        h_epilogue_wide<TM, TN, 2, false, true>(acc, p, row0, col0, lane, stage);       // TOPIQ GatedConv, default gate activation
-      } else if (p.gate) {
-        if (p.res) h_epilogue_wide<TM, TN, -1, true, true>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, -1, false, true>(acc, p, row0, col0, lane, stage);
-      } else {
-        if (p.res) h_epilogue_wide<TM, TN, -1, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, -1, false, false>(acc, p, row0, col0, lane, stage);
-      }
-    }
-  };
-  constexpr bool LEAN = (BM % 64 == 0) && (BN % 64 == 0);
-  static_assert(TN == 1 || (LEAN && MODE == 0), "wide tiles: lean loop, no PReLU epilogue");
-  // 64x64 wave tiles keep ONE fragment set (read after the MFMAs of the slab before, exposed LDS latency covered by the other waves):
-  // 32 VGPRs fewer = three workgroups per CU instead of two, i.e. 144 KB instead of 96 KB of the 160 KB LDS holding DMA data in flight
-  constexpr bool DBUF = (TM * TN < 4);
-  if constexpr (LEAN) {
-    constexpr int NPW = AI + BI;                          // pieces per wave and slab, the same for every wave
-    const unsigned bA0 = lds_base + (unsigned)(aoff + fo0), bA1 = lds_base + (unsigned)(aoff + fo1);
-    const unsigned bB0 = lds_base + (unsigned)(boff + fo0), bB1 = lds_base + (unsigned)(boff + fo1);
-    char* const dA = smem_h + 1024 * wave;                // + SLOT * SLAB + 4096 * j
-    char* const dB = smem_h + BM * 64 + 1024 * wave;
-    unsigned aoffs_l[AI];
-#pragma unroll
-    for (int j = 0; j < AI; ++j) aoffs_l[j] = (ONE_TAP && !(amask[j] & 1ull)) ? 0xFFFFFFF0u : aoffs[j];   // 1x1: row validity folded in
-    int g3 = 0;                                           // slab being issued
-    int l_tb = 0, l_tap = 0; bool l_cok = true;
-    auto lean_begin = [&]() {                             // spatial kernels: tap state of slab g3 (as issue_begin)
-      if constexpr (!ONE_TAP) {
-        const int tb0 = ((kh0 * p.dh * p.W + kw0 * p.dw) * p.ldx + ci0) * 2;
-        int cil = ci0;
-        l_tb = tb0; l_tap = tap0;
-        if (UNITS == 2) {
-          const int tb1 = ((kh1 * p.dh * p.W + kw1 * p.dw) * p.ldx + ci1) * 2;
-          l_tb = upar ? tb1 : tb0; l_tap = upar ? tap1 : tap0; cil = upar ? ci1 : ci0;
-        }
-        l_cok = (cil + cofs) < p.Cin;
-      }
-    };
-    auto lean_end = [&]() {
-      if constexpr (!ONE_TAP) {
-        advance(tap0, kh0, kw0, ci0);
-        if (UNITS == 2) advance(tap1, kh1, kw1, ci1);
-      }
-      ++g3;
-    };
-#define FL_PIECE(SLOT, Q)                                                                                               \
-    {                                                                                                                   \
-      const bool live_ = g3 < nsub;                                                                                     \
-      if constexpr ((Q) < AI) {                                                                                         \
-        if constexpr (ONE_TAP) {                                                                                        \
-          const unsigned off_ = live_ ? aoffs_l[(Q) < AI ? (Q) : 0] : 0xFFFFFFF0u;                      \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 4096 * (Q)), 16, (int)off_, g3 * 64, 0, 0);   \
-        } else {                                                                                                        \
-          const bool ok_ = ((amask[(Q) < AI ? (Q) : 0] >> l_tap) & 1ull) && l_cok && live_;                              \
-          const unsigned off_ = ok_ ? aoffs[(Q) < AI ? (Q) : 0] + (unsigned)l_tb : 0xFFFFFFF0u;                          \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 4096 * (Q)), 16, (int)off_, 0, 0, 0);         \
-        }                                                                                                               \
-      } else {                                                                                                          \
-        const unsigned off_ = live_ ? boffs[(Q) >= AI ? (Q) - AI : 0] : 0xFFFFFFF0u;                    \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(dB + (SLOT) * SLAB + 4096 * ((Q) - AI)), 16, (int)off_, g3 * 64, 0, 0); \
-      }                                                                                                                 \
-    }
-#define FL_READ1(DST, BASE, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "i"(IMM));
-#define FL_READ_FRAGS(SET, SLOT)                                                                                        \
-    {                                                                                                                   \
-      FL_READ1(fa[SET][0], bA0, (SLOT) * SLAB) FL_READ1(fa[SET][1], bA1, (SLOT) * SLAB)                                 \
-      if constexpr (TM > 1) { FL_READ1(fa[SET][2], bA0, (SLOT) * SLAB + 2048) FL_READ1(fa[SET][3], bA1, (SLOT) * SLAB + 2048) } \
-      if constexpr (TM > 2) { FL_READ1(fa[SET][4], bA0, (SLOT) * SLAB + 4096) FL_READ1(fa[SET][5], bA1, (SLOT) * SLAB + 4096)   \
-                              FL_READ1(fa[SET][6], bA0, (SLOT) * SLAB + 6144) FL_READ1(fa[SET][7], bA1, (SLOT) * SLAB + 6144) } \
-      FL_READ1(fb[SET][0], bB0, (SLOT) * SLAB) FL_READ1(fb[SET][1], bB1, (SLOT) * SLAB)                                 \
-      if constexpr (TN > 1) { FL_READ1(fb[SET][2], bB0, (SLOT) * SLAB + 2048) FL_READ1(fb[SET][3], bB1, (SLOT) * SLAB + 2048) } \
-    }
-#define FL_MFMA(SET, Q)                                                                                                 \
-    {                                                                                                                   \
-      constexpr int hh_ = (Q) / (TM * TN), i_ = ((Q) / TN) % TM, j_ = (Q) % TN;                                         \
-      H8 a_, b_;                                                                                                        \
-      a_.f = fa[SET][2 * i_ + hh_]; b_.f = fb[SET][2 * j_ + hh_];                                                       \
-      if constexpr (TN > 1) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_.b, a_.b, acc[i_][j_], 0, 0, 0);  /* transposed tile */ \
-      else acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i_][j_], 0, 0, 0);                     \
-    }
-#define FL_PIECE_AT(SLOT, N, Q)                                                                                          \
-    if constexpr ((N) < NPW && (((N) + 1) * (2 * TM * TN) / (NPW + 1) - 1 < 0 ? 0 : ((N) + 1) * (2 * TM * TN) / (NPW + 1) - 1) == (Q)) { \
-      __builtin_amdgcn_sched_barrier(0);                                                                                 \
-      FL_PIECE(SLOT, N)                                                                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    }
-#define FL_STEP_Q(CUR, SLOTI, Q)                                                                                         \
-    if constexpr ((Q) < 2 * TM * TN) {                                                                                   \
-      FL_MFMA(CUR, Q)                                                                                                    \
-      FL_PIECE_AT(SLOTI, 0, Q) FL_PIECE_AT(SLOTI, 1, Q) FL_PIECE_AT(SLOTI, 2, Q) FL_PIECE_AT(SLOTI, 3, Q) FL_PIECE_AT(SLOTI, 4, Q) FL_PIECE_AT(SLOTI, 5, Q) \
-    }
-    // slab g (fragments in set CUR): wait for this wave's pieces of slab g+1, publish it, read its fragments into the other set,
-    // MFMAs of slab g with the pieces of slab g+3 (ring slot SLOTI = g % 3) between them
-#define FL_SLAB(CUR_, NXT_, SLOTR, SLOTI)                                                                                \
-    {                                                                                                                    \
-      constexpr int CUR = DBUF ? (CUR_) : 0, NXT = DBUF ? (NXT_) : 0;                                                    \
-      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPW) : "memory");                                                         \
-      __builtin_amdgcn_s_barrier();                                                                                      \
-      lean_begin();                                                                                                      \
-      if constexpr (DBUF) { FL_READ_FRAGS(NXT, SLOTR) }                                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                                 \
-      FL_STEP_Q(CUR, SLOTI, 0) FL_STEP_Q(CUR, SLOTI, 1) FL_STEP_Q(CUR, SLOTI, 2) FL_STEP_Q(CUR, SLOTI, 3)                \
-      FL_STEP_Q(CUR, SLOTI, 4) FL_STEP_Q(CUR, SLOTI, 5) FL_STEP_Q(CUR, SLOTI, 6) FL_STEP_Q(CUR, SLOTI, 7)                \
-      FL_STEP_Q(CUR, SLOTI, 8) FL_STEP_Q(CUR, SLOTI, 9) FL_STEP_Q(CUR, SLOTI, 10) FL_STEP_Q(CUR, SLOTI, 11)              \
-      FL_STEP_Q(CUR, SLOTI, 12) FL_STEP_Q(CUR, SLOTI, 13) FL_STEP_Q(CUR, SLOTI, 14) FL_STEP_Q(CUR, SLOTI, 15)            \
-      lean_end();                                                                                                        \
-      if constexpr (!DBUF) { __builtin_amdgcn_sched_barrier(0); FL_READ_FRAGS(NXT, SLOTR) }                              \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
-      __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    }
-    static_assert(NPW <= 6 && 2 * TM * TN <= 16 && TM <= 4 && TN <= 2, "lean loop: piece / MFMA slots");
-    // prologue: slabs 0, 1, 2 (slab 2 is a dummy when nsub == 2)
-#define FL_ISSUE_ALL(SLOT) { lean_begin(); FL_PIECE_ALL(SLOT) lean_end(); }
-#define FL_PIECE_N(SLOT, N) if constexpr ((N) < NPW) FL_PIECE(SLOT, N)
-#define FL_PIECE_ALL(SLOT) FL_PIECE_N(SLOT, 0) FL_PIECE_N(SLOT, 1) FL_PIECE_N(SLOT, 2) FL_PIECE_N(SLOT, 3) FL_PIECE_N(SLOT, 4) FL_PIECE_N(SLOT, 5)
-    FL_ISSUE_ALL(0) FL_ISSUE_ALL(1) FL_ISSUE_ALL(2)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NPW) : "memory");
-    __builtin_amdgcn_s_barrier();
-    FL_READ_FRAGS(0, 0)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    for (int g = 0; g < nsub; g += 6) {      // nsub is even
-      FL_SLAB(0, 1, 1, 0)
-      FL_SLAB(1, 0, 2, 1)
-      if (g + 2 < nsub) {
-        FL_SLAB(0, 1, 0, 2)
-        FL_SLAB(1, 0, 1, 0)
-      }
-      if (g + 4 < nsub) {
-        FL_SLAB(0, 1, 2, 1)
-        FL_SLAB(1, 0, 0, 2)
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy pieces of the tail have landed before the epilogue reuses the ring
-#undef FL_SLAB
-#undef FL_STEP_Q
-#undef FL_PIECE_AT
-#undef FL_MFMA
-#undef FL_READ_FRAGS
-#undef FL_READ1
-#undef FL_PIECE
-#undef FL_ISSUE_ALL
-#undef FL_PIECE_N
-#undef FL_PIECE_ALL
-  } else {
-  issue_step(0);
-  if (nsteps > 1) issue_step(1);
-  if (nsteps > 2) issue_step(2);
-  wait_vm(nsteps > 2 ? 2 * npw : (nsteps > 1 ? npw : 0));
-  __builtin_amdgcn_s_barrier();
-  FH_READ_FRAGS(0, 0)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  for (int g = 0; g < nsub; g += 2) {
-    FH_SLAB(0, 1, g)
-    FH_SLAB(1, 0, g + 1)     // nsub is even (Kp % 64 == 0)
-  }
-  }
-#undef FH_SLAB
-#undef FH_MFMA_BURST_ISSUE
-#undef FH_READ_FRAGS
-  __syncthreads();   // all fragment reads retired before the epilogue reuses the ring as staging
-  if constexpr (TN > 1) {
-    wide_epilogue(m0 + wm * TM * 32, n0 + wn * TN * 32);
-    return;
-  }
-
-  // Two epilogue forms (as in kernels_conv_dma.hip). Narrow wave tiles (TN = 1: the tiles of the HBM-bound short-K layers) keep the
-  // fully unrolled row code with every residual row requested up front (K = 64 -> 256 expand: 4.2 vs 3.8 TB/s against the rolled
-  // form: hipcc drains the outstanding loads at the scalar branches the rolled form has per row). Wide wave tiles take the compact
-  // rolled form.
-  if constexpr (TN == 1) {
-  // ---- epilogue: transpose through a wave-private LDS region, 8 bf16 (16 B) per lane and store ------------------
-    float* smem = reinterpret_cast<float*>(smem_h);
-    if (p.vec_epi) {
-      constexpr int WC = TN * 32, ES = WC + 4, LPR = WC / 8, RPI = 64 / LPR, NIT = 32 / RPI;
-      float* E = smem + wave * 32 * ES;
-      const int lr = lane / LPR, lc = (lane % LPR) * 8;
-      const int colb = n0 + wn * WC + lc;
-      const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
-      const bool cok = colb < climit;
-      const int colc = (colb + 8 <= p.Cout) ? colb : 0;     // per-channel vectors are only read for fully valid groups
-      const bool cfull = colb + 8 <= p.Cout;
-      float sc[8], sf[8];
-  #pragma unroll
-      for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sf[e] = 0.f; }
-      if (p.scale && cfull) {
-        const float4 a = *reinterpret_cast<const float4*>(p.scale + colc), b = *reinterpret_cast<const float4*>(p.scale + colc + 4);
-        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
-      }
-      if (p.shift && cfull) {
-        const float4 a = *reinterpret_cast<const float4*>(p.shift + colc), b = *reinterpret_cast<const float4*>(p.shift + colc + 4);
-        sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
-      }
-      if (!cfull && cok) {   // ragged last group (pad_store): scalar reads of what exists
-  #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (colb + e < p.Cout) { if (p.scale) sc[e] = p.scale[colb + e]; if (p.shift) sf[e] = p.shift[colb + e]; }
-      }
-      float sl[8];
-      if constexpr (MODE == 2) {
-  #pragma unroll
-        for (int e = 0; e < 8; ++e) sl[e] = (colb + e < p.Cout) ? p.slope[colb + e] : 0.f;
-      }
-      // residual rows of ALL the wave's 32-row slabs are requested up front (TM * NIT <= 8 x 16 B per lane): the short-K layers that
-      // carry a residual are bound by their HBM streams, and this doubles the bytes in flight during the LDS transposes
-      constexpr bool RES_AHEAD = (TM * NIT <= 8);
-      uint4 rall[RES_AHEAD ? TM * NIT : 1];
-      if constexpr (RES_AHEAD) {
-        if (p.res) {
-  #pragma unroll
-          for (int i = 0; i < TM; ++i)
-  #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-              const int m = m0 + wm * TM * 32 + i * 32 + lr + it * RPI;
-              const int mc = m < p.M ? m : p.M - 1;
-              rall[i * NIT + it] = *reinterpret_cast<const uint4*>(p.res + (size_t)mc * p.ldr + colc);
-            }
-        }
-      }
-  #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-  #pragma unroll
-        for (int j = 0; j < TN; ++j)
-  #pragma unroll
-          for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
-        const int mrow0 = m0 + wm * TM * 32 + i * 32 + lr;
-        uint4 rv[NIT];
-        float gs[NIT];
-        uint4 gv[NIT];
-  #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int m = mrow0 + it * RPI;
-          const int mc = m < p.M ? m : p.M - 1;
-          if constexpr (RES_AHEAD) { if (p.res) rv[it] = rall[i * NIT + it]; }
-          else if (p.res) rv[it] = *reinterpret_cast<const uint4*>(p.res + (size_t)mc * p.ldr + colc);
-          if (p.gate) {
-            if (p.gate_c1) gs[it] = (float)p.gate[(size_t)mc * p.ldg];
-            else gv[it] = *reinterpret_cast<const uint4*>(p.gate + (size_t)mc * p.ldg + colc);
-          }
-        }
-  #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int m = mrow0 + it * RPI;
-          const float4 v0 = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc]);
-          const float4 v1 = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc + 4]);
-          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-          float rf[8], gf[8];
-          if (p.res) h_unpack8(rv[it], rf);
-          if (p.gate && !p.gate_c1) h_unpack8(gv[it], gf);
-  #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float x = v[e] * sc[e] + sf[e];
-            if (p.res && !p.res_after_act) x += rf[e];
-            if constexpr (MODE == 2) x = x > 0.f ? x : x * sl[e];
-            else x = fe_apply_act_fast(x, p.act);
-            if (p.res && p.res_after_act) x += rf[e];
-            if (p.gate) x *= p.gate_c1 ? gs[it] : gf[e];
-            if (!cfull && colb + e >= p.Cout) x = 0.f;
-            v[e] = x;
-          }
-          H8 o;
-  #pragma unroll
-          for (int e = 0; e < 8; ++e) o.b[e] = (bf16)v[e];
-          if (cok && m < p.M) *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + colb) = o.u;
-        }
-      }
-      return;
-    }
-    // scalar epilogue (Cout or a stride not a multiple of 8): rare, small layers only
-  #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * TN * 32 + j * 32 + r;
-      const bool cok = col < p.Cout;
-      const float sc = (cok && p.scale) ? p.scale[col] : 1.f;
-      const float sf = (cok && p.shift) ? p.shift[col] : 0.f;
-  #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-  #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const int m = m0 + row;
-          if (cok && m < p.M) {
-            float v = acc[i][j][e] * sc + sf;
-            if (p.res && !p.res_after_act) v += (float)p.res[(size_t)m * p.ldr + col];
-            if constexpr (MODE == 2) v = v > 0.f ? v : v * p.slope[col];
-            else v = fe_apply_act(v, p.act);
-            if (p.res && p.res_after_act) v += (float)p.res[(size_t)m * p.ldr + col];
-            if (p.gate) v *= (float)p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
-            p.y[(size_t)m * p.ldy + col] = (bf16)v;
-          }
-        }
-      }
-    }
-  
-    return;
-  }
-}
-
-template <int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
-static void launch_bf16_variant(const ConvParamsH& p, hipStream_t s) {
-  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-  const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
-  constexpr size_t main_lds = (size_t)3 * (BM + BN) * 64;
-  constexpr size_t epi_lds = TN > 1 ? (size_t)4 * (TM * 32) * (TN * 64 + 16)      // wide tiles: bf16 image of every wave's tile
-                                    : (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
-  constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
-  auto kern = conv_bf16_kernel<WGM, WGN, TM, TN, UNITS, MODE, ONE_TAP>;
-  static std::atomic<uint64_t> lds_set{0};
-  ensure_dynamic_lds((const void*)kern, lds, lds_set);
-  const int ntotal = mtiles * ntiles;
-  int gx = ntotal;
-  hipLaunchKernelGGL(kern, dim3(gx, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, ntiles, ntotal);
-  FE_HIP(hipGetLastError());
-}
 
 template <int UNITS>
 static void launch_bf16_tile(const ConvParamsH& p, int tile, bool one_tap, hipStream_t s) {
