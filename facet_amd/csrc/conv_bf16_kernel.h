@@ -153,12 +153,13 @@ __device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const C
 // UNITS = 32 / cb: (channel block, tap) units per 32-element slab. MODE 0 plain, 2 PReLU epilogue.
 // ONE_TAP: 1x1 kernels (GEMMs) - no tap masks, the K offset of a slab goes into the scalar offset of the buffer load.
 template <int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
-__global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM * 32 % 64 == 0 && WGN * TN * 32 % 64 == 0 ? 3 : 2) : 3))) void conv_bf16_kernel(ConvParamsH p, const int ntiles, const int ntotal) {
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM * 32 % 64 == 0 && WGN * TN * 32 % 64 == 0 ? 3 : 2) : 3)))) void conv_bf16_kernel(ConvParamsH p, const int ntiles, const int ntotal) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-  constexpr int AI = (BM + 63) / 64, BI = (BN + 63) / 64;    // DMA pieces per wave per slab (16 rows x 64 B each)
+  constexpr int NW = WGM * WGN;                              // waves per workgroup: 4, or 8 for the 256x256 tile
+  constexpr int AI = (BM + 16 * NW - 1) / (16 * NW), BI = (BN + 16 * NW - 1) / (16 * NW);    // DMA pieces per wave per slab (16 rows x 64 B each)
   constexpr int SLAB = (BM + BN) * 64;                       // bytes per slab
   constexpr int STEP = SLAB;                                 // bytes per ring entry (one slab per barrier: see launch_conv_bf16)
-  static_assert(WGM * WGN == 4, "4 waves");
+  static_assert(NW == 4 || (NW == 8 && TN > 1), "4 waves; 8 for wide wave tiles");
   extern __shared__ __attribute__((aligned(16))) char smem_h[];
 
   if (p.batch > 1) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
     m0 = mt * BM; n0 = nt * BN;
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
-      const int row = 16 * (4 * j + wave) + rsub;
+      const int row = 16 * (NW * j + wave) + rsub;
       const int m = m0 + row;
       const bool valid = (row < BM) && (m < p.M);
       const int mm = valid ? m : 0;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
-      const int row = 16 * (4 * j + wave) + rsub;
+      const int row = 16 * (NW * j + wave) + rsub;
       int n = n0 + row;
       if (n > p.Cout - 1) n = p.Cout - 1;   // columns past Cout are computed on a valid row and discarded
       boffs[j] = (unsigned)(((size_t)n * p.ldw + chunk * 8) * 2);
@@ -273,15 +274,15 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
   auto issue_piece = [&](int q) {      // q < AI: A piece q; else B piece q - AI (q is a compile-time constant at every call site)
     if (q < AI) {
       const int j = q;
-      if (16 * (4 * j + wave) < BM) {
+      if (16 * (NW * j + wave) < BM) {
         const bool ok = ((amask[j] >> i_tap) & 1ull) && i_cok;
         const unsigned off = ok ? aoffs[j] + (unsigned)i_tb : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(iAb + 1024 * (4 * j + wave)), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(iAb + 1024 * (NW * j + wave)), 16, (int)off, 0, 0, 0);
       }
     } else {
       const int j = q - AI;
-      if (16 * (4 * j + wave) < BN)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(iBb + 1024 * (4 * j + wave)), 16, (int)boffs[j], i_tbb, 0, 0);
+      if (16 * (NW * j + wave) < BN)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(iBb + 1024 * (NW * j + wave)), 16, (int)boffs[j], i_tbb, 0, 0);
     }
   };
   auto issue_end = [&]() {
@@ -312,8 +313,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
   const int aoff = (wm * TM * 32 + r) * 64, boff = BM * 64 + (wn * TN * 32 + r) * 64;
 
   // pieces per wave per K-step (for the counted waits)
-  const int npw1 = (BM / 64) + ((16 * wave < BN) ? 1 : 0) + ((BN > 64 && 16 * (4 + wave) < BN) ? 1 : 0);
-  static_assert(BM % 64 == 0 && BN <= 128, "A pieces uniform over waves; B at most two pieces per wave");
+  const int npw1 = (BM / (16 * NW)) + ((16 * wave < BN) ? 1 : 0) + ((BN > 64 && 16 * (NW + wave) < BN) ? 1 : 0);
+  static_assert(BM % (16 * NW) == 0 && BN <= 32 * NW, "A pieces uniform over waves; B at most two pieces per wave");
   const int npw = npw1;
   auto wait_vm = [&](int n) {   // n is wave-uniform
     switch (n) {
@@ -427,7 +428,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
     constexpr int NPW = AI + BI;                          // pieces per wave and slab, the same for every wave
     const unsigned bA0 = lds_base + (unsigned)(aoff + fo0), bA1 = lds_base + (unsigned)(aoff + fo1);
     const unsigned bB0 = lds_base + (unsigned)(boff + fo0), bB1 = lds_base + (unsigned)(boff + fo1);
-    char* const dA = smem_h + 1024 * wave;                // + SLOT * SLAB + 4096 * j
+    const unsigned bA0h = bA0 + 2 * SLAB, bA1h = bA1 + 2 * SLAB, bB0h = bB0 + 2 * SLAB, bB1h = bB1 + 2 * SLAB;
+    (void)bA0h; (void)bA1h; (void)bB0h; (void)bB1h;
+    char* const dA = smem_h + 1024 * wave;                // + SLOT * SLAB + 1024 * NW * j
     char* const dB = smem_h + BM * 64 + 1024 * wave;
     unsigned aoffs_l[AI];
 #pragma unroll
@@ -459,18 +462,21 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM 
       if constexpr ((Q) < AI) {                                                                                         \
         if constexpr (ONE_TAP) {                                                                                        \
           const unsigned off_ = live_ ? aoffs_l[(Q) < AI ? (Q) : 0] : 0xFFFFFFF0u;                      \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 4096 * (Q)), 16, (int)off_, g3 * 64, 0, 0);   \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 1024 * NW * (Q)), 16, (int)off_, g3 * 64, 0, 0);   \
         } else {                                                                                                        \
           const bool ok_ = ((amask[(Q) < AI ? (Q) : 0] >> l_tap) & 1ull) && l_cok && live_;                              \
           const unsigned off_ = ok_ ? aoffs[(Q) < AI ? (Q) : 0] + (unsigned)l_tb : 0xFFFFFFF0u;                          \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 4096 * (Q)), 16, (int)off_, 0, 0, 0);         \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 1024 * NW * (Q)), 16, (int)off_, 0, 0, 0);         \
         }                                                                                                               \
       } else {                                                                                                          \
         const unsigned off_ = live_ ? boffs[(Q) >= AI ? (Q) - AI : 0] : 0xFFFFFFF0u;                    \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(dB + (SLOT) * SLAB + 4096 * ((Q) - AI)), 16, (int)off_, g3 * 64, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(dB + (SLOT) * SLAB + 1024 * NW * ((Q) - AI)), 16, (int)off_, g3 * 64, 0, 0); \
       }                                                                                                                 \
     }
-#define FL_READ1(DST, BASE, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "i"(IMM));
+    // ds_read offsets are 16-bit: ring slot 2 of the 256x256 tile (2 x 32 KB in) is read through a second base register
+#define FL_READ1(DST, BASE, IMM)                                                                                        \
+      if constexpr ((IMM) <= 65535) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "i"(IMM)); }  \
+      else { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE##h), "i"((IMM) - 2 * SLAB)); }
 #define FL_READ_FRAGS(SET, SLOT)                                                                                        \
     {                                                                                                                   \
       FL_READ1(fa[SET][0], bA0, (SLOT) * SLAB) FL_READ1(fa[SET][1], bA1, (SLOT) * SLAB)                                 \
@@ -712,7 +718,7 @@ void launch_bf16_variant(const ConvParamsH& p, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
   constexpr size_t main_lds = (size_t)3 * (BM + BN) * 64;
-  constexpr size_t epi_lds = TN > 1 ? (size_t)4 * (TM * 32) * (TN * 64 + 16)      // wide tiles: bf16 image of every wave's tile
+  constexpr size_t epi_lds = TN > 1 ? (size_t)(WGM * WGN) * (TM * 32) * (TN * 64 + 16)      // wide tiles: bf16 image of every wave's tile
                                     : (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   auto kern = conv_bf16_kernel<WGM, WGN, TM, TN, UNITS, MODE, ONE_TAP>;
@@ -720,7 +726,7 @@ void launch_bf16_variant(const ConvParamsH& p, hipStream_t s) {
   ensure_dynamic_lds((const void*)kern, lds, lds_set);
   const int ntotal = mtiles * ntiles;
   int gx = ntotal;
-  hipLaunchKernelGGL(kern, dim3(gx, p.batch > 1 ? p.batch : 1), dim3(256), lds, s, p, ntiles, ntotal);
+  hipLaunchKernelGGL(kern, dim3(gx, p.batch > 1 ? p.batch : 1), dim3(WGM * WGN * 64), lds, s, p, ntiles, ntotal);
   FE_HIP(hipGetLastError());
 }
 
@@ -732,5 +738,6 @@ extern template void launch_bf16_variant<2, 2, 2, 2, 1, 0, false>(const ConvPara
 extern template void launch_bf16_variant<2, 2, 4, 2, 1, 0, false>(const ConvParamsH&, hipStream_t);
 extern template void launch_bf16_variant<2, 2, 2, 2, 2, 0, false>(const ConvParamsH&, hipStream_t);
 extern template void launch_bf16_variant<2, 2, 4, 2, 2, 0, false>(const ConvParamsH&, hipStream_t);
+extern template void launch_bf16_variant<2, 4, 4, 2, 1, 0, true>(const ConvParamsH&, hipStream_t);     // 256x256, eight waves (kernels_conv_bf16_wide4.hip)
 
 }  // namespace fe

@@ -11,6 +11,7 @@ static void launch_bf16_tile(const ConvParamsH& p, int tile, bool one_tap, hipSt
       switch (tile) {
         case 1: launch_bf16_variant<2, 2, 2, 2, 1, 0, true>(p, s); return;   // 128x128
         case 8: launch_bf16_variant<2, 2, 4, 2, 1, 0, true>(p, s); return;   // 256x128, waves of 128x64
+        case 9: launch_bf16_variant<2, 4, 4, 2, 1, 0, true>(p, s); return;   // 256x256, eight waves of 128x64, one workgroup per CU
         case 7: launch_bf16_variant<2, 2, 2, 1, 1, 0, true>(p, s); return;   // 128x64
         case 4: launch_bf16_variant<2, 2, 1, 1, 1, 0, true>(p, s); return;   // 64x64
         default: break;
@@ -70,13 +71,20 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
     const double e8 = p.K >= 2048 ? 1.00 : (p.K >= 512 ? 1.00 : 0.97);
     const double e1 = p.K >= 2048 ? 0.82 : (p.K >= 512 ? 0.97 : 1.00);
     const double e7 = p.K >= 2048 ? 0.63 : (p.K >= 512 ? 0.81 : 0.88);
-    const Cand wide[4] = {{8, 256, 128, e8}, {1, 128, 128, e1}, {7, 128, 64, e7}, {4, 64, 64, 0.7 * e7}};
+    // 256x256 (eight waves, one workgroup per CU, 7.8 KB of L2 -> LDS fill per MFLOP against 11.7 of the 256x128 tile): GEMM form only
+    const bool gemm_form = ntaps == 1 && p.Cin % 64 == 0 && p.Kp == p.Cin && p.cb == 32;
+    static const double e9_env = getenv("FE_BF16_E9") ? atof(getenv("FE_BF16_E9")) : 0.0;
+    // measured on the ViT-L/14 GEMMs against the 256x128 tile: K = 4096 1042 vs 862 TFLOP/s, K = 1024 824 vs 768, K = 1024 with the GELU
+    // epilogue 714 vs 711 (one workgroup per CU: nothing runs beside its epilogue), batched V^T (N = 257) 502 vs 622
+    const double e9 = (gemm_form && p.K >= 512 && p.batch <= 1) ? (e9_env > 0 ? e9_env : (p.K >= 2048 ? 1.2 : (p.act == ACT_GELU ? 0.95 : 1.05))) : 0.0;
+    const Cand wide[5] = {{8, 256, 128, e8}, {1, 128, 128, e1}, {7, 128, 64, e7}, {4, 64, 64, 0.7 * e7}, {9, 256, 256, e9}};
     static const Cand narrow[2] = {{7, 128, 64, 1.00}, {4, 64, 64, 0.90}};
     static const Cand slim[2] = {{3, 256, 32, 1.00}, {5, 128, 32, 0.92}};
     const Cand* cs = p.Cout > 64 ? wide : (p.Cout > 32 ? narrow : slim);
-    const int nc = p.Cout > 64 ? 4 : 2;
+    const int nc = p.Cout > 64 ? 5 : 2;
     double best = 1e300;
     for (int i = 0; i < nc; ++i) {
+      if (cs[i].eff <= 0.0) continue;
       if (p.Cout > 64 && p.K < 256 && (cs[i].tile == 1 || cs[i].tile == 8)) continue;   // short K: 128x64 (four workgroups per CU)
       const long long wgs = (long long)((p.M + cs[i].bm - 1) / cs[i].bm) * ((p.Cout + cs[i].bn - 1) / cs[i].bn) * p.batch;
       const double cost = (double)((wgs + 255) / 256) * cs[i].bm * cs[i].bn / cs[i].eff;
@@ -87,6 +95,7 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
   // measured 733 vs 1028 images/s on TOPIQ - occupancy beats barrier count here
   static const int force_tile = getenv("FE_BF16_TILE") ? atoi(getenv("FE_BF16_TILE")) : 0;   // A/B hook
   if (force_tile && p.variant == 0 && p.Cout > 32) tile = force_tile;
+  if (tile == 9 && !(ntaps == 1 && p.Cin % 64 == 0 && p.Kp == p.Cin && p.cb == 32)) tile = 8;
   // the wide tiles' epilogue (h_epilogue_wide) addresses y / res / gate through 32-bit buffer offsets in 8-byte quads
   const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
   const unsigned long long ysp = ((unsigned long long)(p.M - 1) * p.ldy + climit) * 2;
@@ -94,7 +103,7 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
   const unsigned long long gsp = p.gate ? ((unsigned long long)(p.M - 1) * p.ldg + (p.gate_c1 ? 1 : p.Cout)) * 2 : 0;
   const bool wide_ok = p.vec_epi && ysp < 0xFFFFFF00ull && rsp < 0xFFFFFF00ull && gsp < 0xFFFFFF00ull && (p.pad_store ? (!p.scale && !p.shift && !p.res && !p.gate) : true);
   p.y_span = (unsigned)ysp; p.r_span = (unsigned)rsp; p.g_span = (unsigned)gsp;
-  if ((tile == 1 || tile == 8) && !wide_ok) tile = 7;
+  if ((tile == 1 || tile == 8 || tile == 9) && !wide_ok) tile = 7;
   const bool one_tap = ntaps == 1 && p.Cin % 64 == 0 && p.Kp == p.Cin;
   if (p.cb == 16) launch_bf16_tile<2>(p, tile, false, s);
   else launch_bf16_tile<1>(p, tile, one_tap, s);
