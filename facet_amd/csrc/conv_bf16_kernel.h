@@ -199,6 +199,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
       const int m = m0 + row;
       const bool valid = (row < BM) && (m < p.M);
       const int mm = valid ? m : 0;
+      if (ONE_TAP && p.unit_stride) {      // 1x1, stride 1, no padding: output pixel m IS input pixel m (no divisions in the prologue)
+        aoffs[j] = (unsigned)(((long long)mm * p.ldx + cofs) * 2);
+        amask[j] = valid ? 1ull : 0ull;
+        continue;
+      }
       const int nimg = mm / HoWo;
       const int rem = mm - nimg * HoWo;
       const int oh = rem / p.Wo, ow = rem - oh * p.Wo;

@@ -169,6 +169,7 @@ struct ConvParamsT {
   int res_after_act;                // 1: y = act(conv*scale+shift) + res ; 0: y = act(conv*scale+shift+res)
   int gate_c1;                      // 1: gate has one channel (broadcast over Cout)
   int vec_epi;                      // set by launch_conv: 16-B vector epilogue is legal
+  int unit_stride;                  // set by the launchers: 1x1 kernel, stride 1, no padding (input pixel index == output pixel index)
   int ldw;                          // weight row stride in elements (0 => Kp); lets an activation matrix act as B
   // batched launches (gridDim.y = batch): b = bo*nb1 + bi; pointer += bo*s2 + bi*s1 (element strides)
   int batch, nb1;

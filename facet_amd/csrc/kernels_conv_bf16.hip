@@ -50,6 +50,8 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
   const unsigned long long ws = ((unsigned long long)p.Cout - 1) * (unsigned long long)p.ldw * 2 + (unsigned long long)p.Kp * 2;
   FE_CHECK(xs < 0xFFFFFF00ull && ws < 0xFFFFFF00ull, "conv_bf16: operand spans exceed 32-bit buffer addressing");
   p.x_span = (unsigned)xs; p.w_span = (unsigned)ws;
+  p.unit_stride = (p.KH == 1 && p.KW == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && p.Ho == p.H && p.Wo == p.W &&
+                   (long long)p.N * p.H * p.W == (long long)p.M) ? 1 : 0;
   auto al16 = [](const void* ptr) { return ((uintptr_t)ptr & 15) == 0; };
   const bool cout_ok = (p.Cout % 8 == 0) || (p.pad_store && ((p.Cout + 7) & ~7) <= p.ldy);
   p.vec_epi = cout_ok && (p.ldy % 8 == 0) && al16(p.y) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) &&

@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
     const int m = m0 + row;
     const bool valid = (row < BM) && (m < p.M);
     const int mm = valid ? m : 0;
+    if (ONE_TAP && p.unit_stride) {      // 1x1, stride 1, no padding: output pixel m IS input pixel m (no divisions in the prologue)
+      aoffs[j] = (unsigned)(((long long)mm * p.ldx + gofs) * 4);
+      amask[j] = valid ? 1ull : 0ull;
+      continue;
+    }
     const int nimg = mm / HoWo;
     const int rem = mm - nimg * HoWo;
     const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
@@ -647,6 +652,8 @@ void launch_conv_dma(const ConvParams& p0, int tile, hipStream_t s) {
   p.buf_ok = !no_buf && xs < 0xFFFFFF00ull && ws < 0xFFFFFF00ull;
   FE_CHECK(p.buf_ok, "conv_dma: operand spans exceed 32-bit buffer addressing (caller must use the register-staged kernel)");
   p.x_span = (unsigned)xs; p.w_span = (unsigned)ws;
+  p.unit_stride = (p.KH == 1 && p.KW == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && p.Ho == p.H && p.Wo == p.W &&
+                   (long long)p.N * p.H * p.W == (long long)p.M) ? 1 : 0;
   if (p.act == ACT_PRELU) {
     FE_CHECK(p.slope, "conv_dma: PReLU without slopes");
     switch (tile) {
