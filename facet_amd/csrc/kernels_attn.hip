@@ -119,10 +119,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float mn = fmaxf(m, tmax);
-    const float alpha = expf(m - mn);          // exp(-inf) = 0 on the first tile
+    const float alpha = __expf(m - mn);          // exp(-inf) = 0 on the first tile
     float psum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { st[e] = expf(st[e] - mn); psum += st[e]; }
+    for (int e = 0; e < 16; ++e) { st[e] = __expf(st[e] - mn); psum += st[e]; }
     psum += __shfl_xor(psum, 32);
     l = l * alpha + psum;
     m = mn;
