@@ -10,6 +10,7 @@
 //   * operands are swapped (weights as A, pixels as B) so every lane ends up holding 4 consecutive output channels of ITS
 //     pixel: the epilogue moves float4 groups (no scalar shuffles) through a wave-private LDS transpose to full-row stores.
 #include "fe_common.h"
+#include <cstdlib>
 
 namespace fe {
 
@@ -120,6 +121,116 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemParamsT<TO> p) {
   }
 }
 
+// The 7x7 stride-2 stem of the bf16 path (the ResNet-50 / ResNet-18 stems of a model committed under bf16): the same tile, patch
+// and epilogue, with the products on the bf16 matrix cores. The fp32 NHWC4 input patch and the fp32 weights are rounded to bf16 on
+// their way into LDS (the same rounding every later layer of that path applies to its input). A tap row is padded to 8 taps (the
+// 8th has zero weights) so taps pair up as (ky, 2t), (ky, 2t+1): one pair = two neighbouring pixels x 4 channels = 16 contiguous,
+// 16-byte aligned bytes of the patch = one ds_read_b128 = a lane's 8 k-values of one v_mfma_f32_32x32x16_bf16 (lanes 0-31 feed
+// pair 2u, lanes 32-63 pair 2u+1). 28 pairs = 14 MFMAs of 32 cycles per 32x32 tile instead of 75 fp32 MFMAs of 64.
+typedef __bf16 stem_bf8 __attribute__((ext_vector_type(8)));
+template <int TN>
+__global__ __launch_bounds__(256, 2) void stem7_bf16_kernel(StemParamsT<bf16> p) {
+  constexpr int K = 7, S = 2, P = 3;
+  constexpr int PH = (STEM_TH - 1) * S + K;            // 21 patch rows
+  constexpr int PW = (STEM_TW - 1) * S + K + 1;        // 69 patch columns + 1: rows stay 16-byte aligned at 8 bytes per pixel
+  constexpr int PAIRS = K * 4;                         // 28 tap pairs
+  constexpr int CO = TN * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint2* patch = reinterpret_cast<uint2*>(smem);                              // [PH][PW] pixels of 4 bf16
+  uint4* wl = reinterpret_cast<uint4*>(smem) + (PH * PW + 1) / 2;             // [PAIRS][CO] entries of 8 bf16 (2 taps x 4 channels)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int ox0 = blockIdx.x * STEM_TW, oy0 = blockIdx.y * STEM_TH, img = blockIdx.z;
+  auto pack4 = [](const float4 v) -> uint2 {
+    union { bf16 b[4]; uint2 u; } o;
+    o.b[0] = (bf16)v.x; o.b[1] = (bf16)v.y; o.b[2] = (bf16)v.z; o.b[3] = (bf16)v.w;
+    return o.u;
+  };
+  const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
+  for (int i = t; i < PH * PW; i += 256) {
+    const int py = i / PW, px = i - py * PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+      v = *reinterpret_cast<const float4*>(p.x + (((size_t)img * p.H + iy) * p.W + ix) * p.ldx);
+    v.w = 0.f;
+    patch[i] = pack4(v);
+  }
+  for (int i = t; i < PAIRS * CO; i += 256) {          // p.w: [50 taps][CO][4] fp32 (the fp32 stem's layout)
+    const int pair = i / CO, co = i - pair * CO;
+    const int ky = pair >> 2, kx = (pair & 3) * 2;
+    const float4 w0 = *reinterpret_cast<const float4*>(p.w + ((size_t)(ky * K + kx) * CO + co) * 4);
+    float4 w1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kx + 1 < K) w1 = *reinterpret_cast<const float4*>(p.w + ((size_t)(ky * K + kx + 1) * CO + co) * 4);
+    const uint2 a = pack4(w0), b = pack4(w1);
+    wl[i] = make_uint4(a.x, a.y, b.x, b.y);
+  }
+  __syncthreads();
+
+  stem_f32x16 acc[TN][2];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+  const uint2* prow[2] = {patch + (size_t)((2 * wave + 0) * S) * PW + r * S, patch + (size_t)((2 * wave + 1) * S) * PW + r * S};
+#pragma unroll
+  for (int u = 0; u < PAIRS / 2; ++u) {
+    const int pair = 2 * u + h;
+    const int ky = pair >> 2, kx = (pair & 3) * 2;
+    union { uint4 u4; stem_bf8 b; } a[TN], b[2];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) a[j].u4 = wl[pair * CO + j * 32 + r];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i].u4 = *reinterpret_cast<const uint4*>(prow[i] + ky * PW + kx);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j].b, b[i].b, acc[j][i], 0, 0, 0);
+  }
+
+  // ---- epilogue: as stem_kernel (lane (r, h) holds couts (e&3) + 8(e>>2) + 4h of pixel r) --------------------------------
+  __syncthreads();
+  constexpr int ES = CO + 4, LPP = CO / 4;
+  float* E = smem + (size_t)wave * 64 * ES;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(E + (size_t)(i * 32 + r) * ES + j * 32 + 8 * g + 4 * h) =
+            make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+  const int c4 = (lane % LPP) * 4;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + c4);
+  if (p.shift) sf = *reinterpret_cast<const float4*>(p.shift + c4);
+  constexpr int PPI = 64 / LPP;
+#pragma unroll
+  for (int it = 0; it < 64 / PPI; ++it) {
+    const int px = it * PPI + lane / LPP;
+    const int oy = oy0 + 2 * wave + (px >> 5), ox = ox0 + (px & 31);
+    float4 v = *reinterpret_cast<const float4*>(E + (size_t)px * ES + c4);
+    v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+    if (p.act == 1) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+    if (oy < p.Ho && ox < p.Wo) st4(p.y + (((size_t)img * p.Ho + oy) * p.Wo + ox) * p.ldy + c4, v);
+  }
+}
+
+template <int TN>
+static void launch_stem7_bf16(const StemParamsT<bf16>& p, hipStream_t s) {
+  constexpr int PH = (STEM_TH - 1) * 2 + 7, PW = (STEM_TW - 1) * 2 + 7 + 1;
+  constexpr size_t main_lds = (size_t)((PH * PW + 1) / 2) * 16 + (size_t)28 * TN * 32 * 16;
+  constexpr size_t epi_lds = (size_t)4 * 64 * (TN * 32 + 4) * sizeof(float);
+  constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
+  static std::atomic<uint64_t> lds_set{0};
+  ensure_dynamic_lds((const void*)stem7_bf16_kernel<TN>, lds, lds_set);
+  const dim3 grid((p.Wo + STEM_TW - 1) / STEM_TW, (p.Ho + STEM_TH - 1) / STEM_TH, p.N);
+  hipLaunchKernelGGL((stem7_bf16_kernel<TN>), grid, dim3(256), lds, s, p);
+  FE_HIP(hipGetLastError());
+}
+
 template <int TN, int K, int S, class TO>
 static void launch_stem_t(const StemParamsT<TO>& p, hipStream_t s) {
   constexpr int PH = (STEM_TH - 1) * S + K, PW = (STEM_TW - 1) * S + K, T2 = (K * K + 1) & ~1;
@@ -144,6 +255,13 @@ bool launch_stem(const float* x, int ldx, int N, int H, int W, const float* wste
     return false;
   StemParamsT<TO> p{x, ldx, wstem, scale, shift, y, ldy, slope, N, H, W, Ho, Wo, Cout, act};
   const int key = k * 10 + stride;
+  if constexpr (sizeof(TO) == 2) {      // a stem that feeds the bf16 path: 7x7 / 2 on the bf16 matrix cores
+    static const bool f32_stem = getenv("FE_BF16_STEM_F32") != nullptr;      // A/B hook: keep the fp32 products
+    if (key == 72 && act != 2 && !f32_stem) {
+      if (Cout == 64) launch_stem7_bf16<2>(p, s); else launch_stem7_bf16<1>(p, s);
+      return true;
+    }
+  }
   if (Cout == 64) {
     if (key == 72) launch_stem_t<2, 7, 2, TO>(p, s);
     else if (key == 31) launch_stem_t<2, 3, 1, TO>(p, s);
