@@ -424,7 +424,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
       }
     }
   };
-  constexpr bool LEAN = (BM % 64 == 0) && (BN % 64 == 0);
+  // (32-column tiles: only waves 0 and 1 own a B piece; the other two issue an out-of-range dummy piece into a scratch KiB behind the
+  // ring, so every wave still counts the same number of pieces per slab)
+  constexpr bool LEAN = (BM % (16 * NW) == 0) && (BN % (16 * NW) == 0 || (BN == 32 && NW == 4));
   static_assert(TN == 1 || (LEAN && MODE == 0), "wide tiles: lean loop, no PReLU epilogue");
   // 64x64 wave tiles keep ONE fragment set (read after the MFMAs of the slab before, exposed LDS latency covered by the other waves):
   // 32 VGPRs fewer = three workgroups per CU instead of two, i.e. 144 KB instead of 96 KB of the 160 KB LDS holding DMA data in flight
@@ -474,8 +476,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 1024 * NW * (Q)), 16, (int)off_, 0, 0, 0);         \
         }                                                                                                               \
       } else {                                                                                                          \
-        const unsigned off_ = live_ ? boffs[(Q) >= AI ? (Q) - AI : 0] : 0xFFFFFFF0u;                    \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(dB + (SLOT) * SLAB + 1024 * NW * ((Q) - AI)), 16, (int)off_, g3 * 64, 0, 0); \
+        const bool mine_ = BN >= 16 * NW || 16 * wave < BN;                                                             \
+        const unsigned off_ = (live_ && mine_) ? boffs[(Q) >= AI ? (Q) - AI : 0] : 0xFFFFFFF0u;                         \
+        char* const dst_ = mine_ ? dB + (SLOT) * SLAB + 1024 * NW * ((Q) - AI) : smem_h + 3 * SLAB + 1024 * wave;       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)dst_, 16, (int)off_, g3 * 64, 0, 0);                    \
       }                                                                                                                 \
     }
     // ds_read offsets are 16-bit: ring slot 2 of the 256x256 tile (2 x 32 KB in) is read through a second base register
@@ -722,7 +726,7 @@ template <int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TA
 void launch_bf16_variant(const ConvParamsH& p, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
-  constexpr size_t main_lds = (size_t)3 * (BM + BN) * 64;
+  constexpr size_t main_lds = (size_t)3 * (BM + BN) * 64 + (BN == 32 ? 4096 : 0);      // + the dummy pieces' scratch (32-column tiles)
   constexpr size_t epi_lds = TN > 1 ? (size_t)(WGM * WGN) * (TM * 32) * (TN * 64 + 16)      // wide tiles: bf16 image of every wave's tile
                                     : (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;

@@ -260,7 +260,9 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
   // `base + immediate`, the counted wait an immediate; the last three slabs still issue their pieces, with out-of-range offsets (zero
   // fill, no memory traffic), so every iteration is the same straight-line code (~45 instead of ~130 instructions around the 16-32
   // MFMAs of a slab); 1x1 kernels pass the slab's K offset as the scalar offset of the load.
-  constexpr bool LEAN = (MODE != 1) && (BM % 64 == 0) && (BN % 64 == 0) && (TM <= 2) && (TN <= 2);
+  // (32-column tiles: only waves 0 and 1 own a B piece; the other two issue an out-of-range dummy piece into a scratch KiB behind the
+  // ring, so every wave still counts the same number of pieces per slab)
+  constexpr bool LEAN = (MODE != 1) && (BM % 64 == 0) && (BN % 64 == 0 || BN == 32) && (TM <= 2) && (TN <= 2);
   if constexpr (LEAN) {
     constexpr int NPW = AI + BI;
     constexpr int SLABB = SLAB * 4;                         // bytes per ring slot
@@ -300,8 +302,10 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 4 : (TM * TN >= 8 ? 2 : (TM * TN 
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dA + (SLOT) * SLABB + 4096 * (Q)), 16, (int)off_, 0, 0, 0);         \
         }                                                                                                               \
       } else {                                                                                                          \
-        const unsigned off_ = live_ ? boffs[(Q) >= AI ? (Q) - AI : 0] : 0xFFFFFFF0u;                                    \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dB + (SLOT) * SLABB + 4096 * ((Q) - AI)), 16, (int)off_, g3 * 64, 0, 0); \
+        const bool mine_ = BN >= 64 || 16 * wave < BN;                                                                  \
+        const unsigned off_ = (live_ && mine_) ? boffs[(Q) >= AI ? (Q) - AI : 0] : 0xFFFFFFF0u;                         \
+        char* const dst_ = mine_ ? dB + (SLOT) * SLABB + 4096 * ((Q) - AI) : reinterpret_cast<char*>(smem) + 3 * SLABB + 1024 * wave; \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst_, 16, (int)off_, g3 * 64, 0, 0);                      \
       }                                                                                                                 \
     }
 #define FL_READ1(DST, BASE, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "i"(IMM));
@@ -632,7 +636,7 @@ template <int WGM, int WGN, int TM, int TN, int MODE = 0, bool ONE_TAP = false>
 static void launch_dma_variant(const ConvParams& p, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
-  constexpr size_t main_lds = (size_t)(MODE == 1 ? 2 : 3) * (BM + BN) * 16 * sizeof(float);
+  constexpr size_t main_lds = (size_t)(MODE == 1 ? 2 : 3) * (BM + BN) * 16 * sizeof(float) + (BN == 32 ? 4096 : 0);   // + dummy-piece scratch
   constexpr size_t epi_lds = (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   auto kern = conv_dma_kernel<WGM, WGN, TM, TN, MODE, ONE_TAP>;
