@@ -9,6 +9,8 @@ Tolerances, stated once here and in DESIGN.md:
     CLIP embedding cosine >= 0.999, SAMP logits / attributes / distribution within 3e-2 absolute of values of order 1.
     north_star's 1e-3 is stated for fp32 and is NOT claimed for bf16.
 """
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -60,7 +62,7 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c))
 def test_bf16_contraction_matches_fp32_on_rounded_inputs(eng16, case):
     n, cin, h, w, cout, k, stride, pad, dil, act, with_res = case
-    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))      # stable across processes (str hashes are salted)
     x = _r16(rng.normal(0, 1, (n, cin, h, w)))
     wt = _r16(rng.normal(0, 1.0 / np.sqrt(cin * k * k), (cout, cin, k, k)))
     scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
@@ -139,10 +141,11 @@ def test_topiq_bf16_score_against_fp32_oracle(eng16, hw, n):
     assert rel.max() < 2e-2
 
 
-def test_topiq_bf16_pyramid_levels(eng16):
+@pytest.mark.parametrize("hw", [(128, 160), (97, 139)])      # the odd size: ragged stem tiles (8 x 32 outputs), ragged pooling, ragged M everywhere
+def test_topiq_bf16_pyramid_levels(eng16, hw):
     from oracle.resnet import ResNet50Features
     sd = _load(eng16, ["topiq"], 3)
-    imgs = synthetic_images(1, 2, 128, 160)
+    imgs = synthetic_images(1, 2, *hw)
     net = ResNet50Features().eval()
     net.load_state_dict({k[len("semantic_model."):]: torch.from_numpy(v) for k, v in sd["topiq"].items() if k.startswith("semantic_model.")})
     m, s = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
