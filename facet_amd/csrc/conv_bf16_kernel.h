@@ -158,7 +158,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
   constexpr int NW = WGM * WGN;                              // waves per workgroup: 4, or 8 for the 256x256 tile
   constexpr int AI = (BM + 16 * NW - 1) / (16 * NW), BI = (BN + 16 * NW - 1) / (16 * NW);    // DMA pieces per wave per slab (16 rows x 64 B each)
   constexpr int SLAB = (BM + BN) * 64;                       // bytes per slab
-  constexpr int STEP = SLAB;                                 // bytes per ring entry (one slab per barrier: see launch_conv_bf16)
   static_assert(NW == 4 || (NW == 8 && TN > 1), "4 waves; 8 for wide wave tiles");
   extern __shared__ __attribute__((aligned(16))) char smem_h[];
 
@@ -255,51 +254,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
     }
   };
   const int nsub = p.Kp / 32;            // slabs; Kp % 64 == 0
-  const int nsteps = nsub;
-
-  // One slab = AI A-pieces + BI B-pieces per wave. issue_begin fixes the slab's addresses, issue_piece(q) launches one 1-KiB LDS-DMA,
-  // issue_end advances the unit state: the main loop spreads the pieces BETWEEN the MFMAs of the current slab (a piece costs its wave
-  // 60-185 cycles of issue, an MFMA occupies the pipe for 32: issued in front of the burst the pieces took longer than the burst).
-  char* iAb = nullptr; char* iBb = nullptr;
-  int i_tb = 0, i_tap = 0, i_tbb = 0;
-  bool i_cok = true;
-  auto issue_begin = [&](int g) {
-    iAb = smem_h + (g % 3) * STEP;
-    iBb = iAb + BM * 64;
-    const int tb0 = ((kh0 * p.dh * p.W + kw0 * p.dw) * p.ldx + ci0) * 2;
-    int cil = ci0;
-    i_tb = tb0; i_tap = tap0;
-    if (UNITS == 2) {
-      const int tb1 = ((kh1 * p.dh * p.W + kw1 * p.dw) * p.ldx + ci1) * 2;
-      i_tb = upar ? tb1 : tb0; i_tap = upar ? tap1 : tap0; cil = upar ? ci1 : ci0;
-    }
-    i_cok = (cil + cofs) < p.Cin;   // chunk inside the channel range (the K tail and 1x1 kernels with Cin % 32 != 0)
-    i_tbb = g * 64;
-  };
-  auto issue_piece = [&](int q) {      // q < AI: A piece q; else B piece q - AI (q is a compile-time constant at every call site)
-    if (q < AI) {
-      const int j = q;
-      if (16 * (NW * j + wave) < BM) {
-        const bool ok = ((amask[j] >> i_tap) & 1ull) && i_cok;
-        const unsigned off = ok ? aoffs[j] + (unsigned)i_tb : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(iAb + 1024 * (NW * j + wave)), 16, (int)off, 0, 0, 0);
-      }
-    } else {
-      const int j = q - AI;
-      if (16 * (NW * j + wave) < BN)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (h_lptr_t)(iBb + 1024 * (NW * j + wave)), 16, (int)boffs[j], i_tbb, 0, 0);
-    }
-  };
-  auto issue_end = [&]() {
-    advance(tap0, kh0, kw0, ci0);
-    if (UNITS == 2) advance(tap1, kh1, kw1, ci1);
-  };
-  auto issue_step = [&](int st) {      // whole slab at once (prologue)
-    issue_begin(st);
-#pragma unroll
-    for (int q = 0; q < AI + BI; ++q) issue_piece(q);
-    issue_end();
-  };
 
   h_f32x16 acc[TM][TN];
   auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -317,86 +271,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
   const int fo0 = ((h ^ sw) << 4), fo1 = fo0 ^ 32;
   const int aoff = (wm * TM * 32 + r) * 64, boff = BM * 64 + (wn * TN * 32 + r) * 64;
 
-  // pieces per wave per K-step (for the counted waits)
-  const int npw1 = (BM / (16 * NW)) + ((16 * wave < BN) ? 1 : 0) + ((BN > 64 && 16 * (NW + wave) < BN) ? 1 : 0);
-  static_assert(BM % (16 * NW) == 0 && BN <= 32 * NW, "A pieces uniform over waves; B at most two pieces per wave");
-  const int npw = npw1;
-  auto wait_vm = [&](int n) {   // n is wave-uniform
-    switch (n) {
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-      case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-      case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-  };
   const unsigned lds_base = (unsigned)(size_t)(h_lptr_t)smem_h;
   h_v4f fa[2][2 * TM], fb[2][2 * TN];   // [register set][fragment]; indices are compile-time everywhere below
-#define FH_READ_FRAGS(SET, G)                                                                                        \
-  {                                                                                                                  \
-    const unsigned sb_ = lds_base + (unsigned)(((G) % 3) * STEP);                         \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                 \
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET][2 * i]) : "v"(sb_ + (unsigned)(aoff + i * 32 * 64 + fo0)));      \
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET][2 * i + 1]) : "v"(sb_ + (unsigned)(aoff + i * 32 * 64 + fo1)));  \
-    }                                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                 \
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET][2 * j]) : "v"(sb_ + (unsigned)(boff + j * 32 * 64 + fo0)));      \
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET][2 * j + 1]) : "v"(sb_ + (unsigned)(boff + j * 32 * 64 + fo1)));  \
-    }                                                                                                                \
-  }
-  // MFMA burst of one slab with this wave's DMA pieces of slab g+3 spread between the MFMAs (DO: block-uniform, false in the tail).
-  // Piece n goes behind MFMA max(0, (n + 1) * Q / (NP + 1) - 1); sched_barrier pins the order (hipcc otherwise gathers the loads in
-  // front of the MFMAs again).
-#define FH_MFMA_BURST_ISSUE(SET, DO)                                                                                 \
-  {                                                                                                                  \
-    constexpr int Q_ = 2 * TM * TN, NP_ = AI + BI;                                                                   \
-    _Pragma("unroll") for (int q_ = 0; q_ < Q_; ++q_) {                                                              \
-      const int hh = q_ / (TM * TN), i = (q_ / TN) % TM, j = q_ % TN;                                                \
-      H8 a_, b_;                                                                                                     \
-      a_.f = fa[SET][2 * i + hh]; b_.f = fb[SET][2 * j + hh];                                                        \
-      if constexpr (TN > 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_.b, a_.b, acc[i][j], 0, 0, 0);   /* transposed tile */ \
-      else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i][j], 0, 0, 0);                      \
-      _Pragma("unroll") for (int n_ = 0; n_ < NP_; ++n_)                                                             \
-        if (((n_ + 1) * Q_ / (NP_ + 1) - 1 < 0 ? 0 : (n_ + 1) * Q_ / (NP_ + 1) - 1) == q_) {                         \
-          __builtin_amdgcn_sched_barrier(0);                                                                         \
-          if (DO) issue_piece(n_);                                                                                   \
-          __builtin_amdgcn_sched_barrier(0);                                                                         \
-        }                                                                                                            \
-    }                                                                                                                \
-  }
-  // one slab: fragments of slab g are in register set CUR; slab g+1 is read into NXT under the MFMAs of g. Entering slab g+1 first
-  // waits for this wave's DMA pieces of it, then one barrier publishes it (and retires every wave's reads of slab g, whose buffer
-  // the pieces issued during this burst overwrite).
-#define FH_SLAB(CUR, NXT, G)                                                                                         \
-  {                                                                                                                  \
-    const int g_ = (G);                                                                                              \
-    bool do_issue_ = false;                                                                                          \
-    if (g_ + 1 < nsub) {                                                                                             \
-      wait_vm(g_ + 2 < nsub ? npw : 0);                                                                              \
-      __builtin_amdgcn_s_barrier();                                                                                  \
-      do_issue_ = g_ + 3 < nsub;                                                                                     \
-      if (do_issue_) issue_begin(g_ + 3);                                                                            \
-      FH_READ_FRAGS(NXT, g_ + 1)                                                                                     \
-    }                                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                               \
-    FH_MFMA_BURST_ISSUE(CUR, do_issue_)                                                                              \
-    if (do_issue_) issue_end();                                                                                      \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                               \
-  }
-
-  // Tiles whose waves all issue the same number of pieces (BM, BN multiples of 64) take the LEAN loop: the generic one spends ~125
-  // instructions per slab and wave (scalar branches around every piece, a switch for the counted wait, modulo-3 ring arithmetic, one
-  // VALU address per LDS read) on 4-8 MFMAs of 32 cycles - with four waves per SIMD the instruction issue, not the matrix pipe, set
-  // the pace (PMC: SQ_ACTIVE_INST_ANY 0.35 of the wave cycles). Lean form: unrolled by 6 = ring slot (mod 3) x register set (mod 2),
+  // The main loop. Its first form spent ~125 instructions per slab and wave (scalar branches around every piece, a switch for the
+  // counted wait, modulo-3 ring arithmetic, one VALU address per LDS read) on 4-8 MFMAs of 32 cycles - with four waves per SIMD the
+  // instruction issue, not the matrix pipe, set the pace (PMC: SQ_ACTIVE_INST_ANY 0.35 of the wave cycles). This form is unrolled by 6 = ring slot (mod 3) x register set (mod 2),
   // so every LDS read is `base + immediate` and every DMA destination `base + immediate`; the counted wait is an immediate; the last
   // three slabs still "issue" their pieces, with out-of-range offsets (zero fill, no memory traffic), so every iteration is the
   // same straight-line code; 1x1 kernels pass the slab's K offset as the scalar offset of the load (no VALU at all per piece).
@@ -431,7 +310,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
   // 64x64 wave tiles keep ONE fragment set (read after the MFMAs of the slab before, exposed LDS latency covered by the other waves):
   // 32 VGPRs fewer = three workgroups per CU instead of two, i.e. 144 KB instead of 96 KB of the 160 KB LDS holding DMA data in flight
   constexpr bool DBUF = (TM * TN < 4);
-  if constexpr (LEAN) {
+  static_assert(LEAN, "every instantiated tile has a uniform piece count per wave");
+  {      // (scope of the main-loop macros' locals)
     constexpr int NPW = AI + BI;                          // pieces per wave and slab, the same for every wave
     const unsigned bA0 = lds_base + (unsigned)(aoff + fo0), bA1 = lds_base + (unsigned)(aoff + fo1);
     const unsigned bB0 = lds_base + (unsigned)(boff + fo0), bB1 = lds_base + (unsigned)(boff + fo1);
@@ -444,7 +324,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
     for (int j = 0; j < AI; ++j) aoffs_l[j] = (ONE_TAP && !(amask[j] & 1ull)) ? 0xFFFFFFF0u : aoffs[j];   // 1x1: row validity folded in
     int g3 = 0;                                           // slab being issued
     int l_tb = 0, l_tap = 0; bool l_cok = true;
-    auto lean_begin = [&]() {                             // spatial kernels: tap state of slab g3 (as issue_begin)
+    auto lean_begin = [&]() {                             // spatial kernels: tap state of slab g3
       if constexpr (!ONE_TAP) {
         const int tb0 = ((kh0 * p.dh * p.W + kw0 * p.dw) * p.ldx + ci0) * 2;
         int cil = ci0;
@@ -567,23 +447,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
 #undef FL_ISSUE_ALL
 #undef FL_PIECE_N
 #undef FL_PIECE_ALL
-  } else {
-  issue_step(0);
-  if (nsteps > 1) issue_step(1);
-  if (nsteps > 2) issue_step(2);
-  wait_vm(nsteps > 2 ? 2 * npw : (nsteps > 1 ? npw : 0));
-  __builtin_amdgcn_s_barrier();
-  FH_READ_FRAGS(0, 0)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  for (int g = 0; g < nsub; g += 2) {
-    FH_SLAB(0, 1, g)
-    FH_SLAB(1, 0, g + 1)     // nsub is even (Kp % 64 == 0)
   }
-  }
-#undef FH_SLAB
-#undef FH_MFMA_BURST_ISSUE
-#undef FH_READ_FRAGS
   __syncthreads();   // all fragment reads retired before the epilogue reuses the ring as staging
   if constexpr (TN > 1) {
     wide_epilogue(m0 + wm * TM * 32, n0 + wn * TN * 32);
