@@ -83,3 +83,33 @@ def test_bench_self_launches_its_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "nope"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The driver parses ONE JSON line from `python bench.py`: the line committed under profiles/ (the end-of-round run) must carry
+    every field of the contract, incl. the roofline and cpu_baseline objects, and its numbers must be consistent with each other."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    logs = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_default.json.log")))
+    assert logs, "no committed bench line"
+    line = [l for l in open(logs[-1]) if l.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["value"] > 0
+    # value = images of the timed region / its time
+    images = d["config"]["global_batch"] * d["steps"]
+    assert abs(d["value"] - images / (d["ms_per_step"] * d["steps"] * 1e-3)) < 0.02 * d["value"]
+    for name, sub in d.get("sub", {}).items():
+        assert sub["value"] > 0 and "roofline" in sub and "workload" in sub["config"], name
