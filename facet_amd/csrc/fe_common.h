@@ -230,6 +230,33 @@ bool launch_stem(const float* x, int ldx, int N, int H, int W, const float* wste
 void launch_conv_narrow(const ConvParams& p, hipStream_t s);            // Cout <= 4, no MFMA (kernels_misc.hip)
 void launch_conv_dma(const ConvParams& p, int tile, hipStream_t s);  // LDS-DMA fast path (kernels_conv_dma.hip)
 void launch_conv_bf16(const ConvParamsH& p, hipStream_t s);          // bf16 MFMA implicit GEMM (kernels_conv_bf16.hip)
+// A convolution over a batch of images whose input, output or residual tensor outgrows the 32-bit buffer addressing of the LDS-DMA
+// kernels (4 GiB: e.g. 64 fp32 images of 512 x 512 x 64) is issued as several launches over image groups that fit. Returns false when the
+// problem is not an image batch (GEMMs, batched launches) or a single image is already too large.
+template <class T, class Launch>
+inline bool conv_split_by_images(const ConvParamsT<T>& p, Launch&& launch) {
+  if (p.batch > 1 || p.N <= 1 || (long long)p.N * p.Ho * p.Wo != (long long)p.M) return false;
+  const unsigned long long in_img = (unsigned long long)p.H * p.W * p.ldx * sizeof(T);
+  const unsigned long long out_img = (unsigned long long)p.Ho * p.Wo * (unsigned long long)(p.ldy > p.ldr ? p.ldy : p.ldr) * sizeof(T);
+  const unsigned long long per_img = in_img > out_img ? in_img : out_img;
+  constexpr unsigned long long LIMIT = 0xF0000000ull;
+  if (per_img >= LIMIT) return false;
+  const int ng = (int)(LIMIT / per_img);
+  if (ng >= p.N) return false;
+  for (int i0 = 0; i0 < p.N; i0 += ng) {
+    ConvParamsT<T> q = p;
+    const int n = ng < p.N - i0 ? ng : p.N - i0;
+    const size_t opix = (size_t)i0 * p.Ho * p.Wo;
+    q.N = n; q.M = n * p.Ho * p.Wo;
+    q.x = p.x + (size_t)i0 * p.H * p.W * p.ldx;
+    q.y = p.y + opix * p.ldy;
+    if (p.res) q.res = p.res + opix * p.ldr;
+    if (p.gate) q.gate = p.gate + opix * p.ldg;
+    launch(q);
+  }
+  return true;
+}
+
 double conv_flops(const ConvParams& p);
 
 // ---------------------------------------------------------------------------------------

@@ -308,6 +308,10 @@ void launch_conv(const ConvParams& p, hipStream_t s) {
   if (q.batch < 1) q.batch = 1;
   if (q.nb1 < 1) q.nb1 = 1;
   FE_CHECK(q.ldw % 4 == 0, "conv: ldw=%d must be a multiple of 4", q.ldw);
+  {      // tensors past 4 GiB: image groups that fit the LDS-DMA kernels' buffer addressing (instead of the register-staged fallback)
+    const unsigned long long xsp = (unsigned long long)p.N * p.H * p.W * (unsigned long long)p.ldx * 4;
+    if (xsp >= 0xFFFFFF00ull && p.variant == 0 && conv_split_by_images(q, [&](const ConvParams& sub) { launch_conv(sub, s); })) return;
+  }
   FE_CHECK(q.batch == 1 || (!q.res && !q.gate && !q.scale), "conv: batched launches take no res/gate/scale");
   auto al16 = [](const void* ptr) { return ((uintptr_t)ptr & 15) == 0; };
   q.vec_epi = (p.Cout % 4 == 0) && (p.ldy % 4 == 0) && al16(p.y) && (!p.res || (p.ldr % 4 == 0 && al16(p.res))) &&

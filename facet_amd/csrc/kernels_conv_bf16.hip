@@ -48,6 +48,10 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
   FE_CHECK((long long)p.N * p.H * p.W < (1ll << 31), "conv_bf16: too many input pixels");
   const unsigned long long xs = ((unsigned long long)p.N * p.H * p.W - 1) * (unsigned long long)p.ldx * 2 + (unsigned long long)p.Cin * 2;
   const unsigned long long ws = ((unsigned long long)p.Cout - 1) * (unsigned long long)p.ldw * 2 + (unsigned long long)p.Kp * 2;
+  {      // tensors past 4 GiB (input, or the output / residual the wide tiles address through buffers): image groups that fit
+    const unsigned long long ysp = (unsigned long long)p.M * (unsigned long long)(p.ldy > p.ldr ? p.ldy : p.ldr) * 2;
+    if ((xs >= 0xFFFFFF00ull || ysp >= 0xFFFFFF00ull) && conv_split_by_images(p, [&](const ConvParamsH& sub) { launch_conv_bf16(sub, s); })) return;
+  }
   FE_CHECK(xs < 0xFFFFFF00ull && ws < 0xFFFFFF00ull, "conv_bf16: operand spans exceed 32-bit buffer addressing");
   p.x_span = (unsigned)xs; p.w_span = (unsigned)ws;
   p.unit_stride = (p.KH == 1 && p.KW == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && p.Ho == p.H && p.Wo == p.W &&
