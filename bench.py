@@ -267,7 +267,8 @@ def main():
         if mask & 4:
             e.load_weights(FE_MODEL_U2NETP, synthetic_state_dict("u2netp", seed=3))
             e.load_weights(FE_MODEL_SAMP, synthetic_state_dict("samp_net", seed=3))
-        e.set_microbatch(args.microbatch)
+        # bf16 activations are half the bytes: the same arena holds twice the images per micro-batch (fewer, larger launches)
+        e.set_microbatch(args.microbatch * 2 if precision == "bf16" else args.microbatch)
         return e
 
     def make_face_engine():
@@ -414,7 +415,7 @@ def main():
             "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_text(primary, B, HW, args.dtype),
-                       "global_batch": B * world, "image_size": HW, "microbatch": args.microbatch,
+                       "global_batch": B * world, "image_size": HW, "microbatch": args.microbatch * 2 if args.dtype == "bf16" else args.microbatch,
                        "parallelism": f"image-sharded x{world}, one RCCL all-gather of per-image records per step (device buffers)",
                        "weights": "seeded synthetic checkpoints (no weight files offline)"},
             "roofline": roofline(primary, args.steps, ev_ms, flops, flops_exec, eng, args.dtype),
@@ -435,7 +436,7 @@ def main():
         dts, evs, fl, fx = measure(wl, s_steps, s_warm, e)
         sub[key] = {"value": round(B * s_steps / dts, 2), "unit": "images/s", "steps": s_steps, "warmup": s_warm,
                     "ms_per_step": round(dts / s_steps * 1e3, 3), "dtype": "f32 + bf16 CLIP" if dt == "clip_bf16" else dt,
-                    "config": {"workload": workload_text(wl, B, HW, dt)},
+                    "config": {"workload": workload_text(wl, B, HW, dt), "microbatch": args.microbatch * 2 if dt == "bf16" else args.microbatch},
                     "roofline": mixed_roofline(s_steps, evs, fl, fx, e) if dt == "clip_bf16" else roofline(wl, s_steps, evs, fl, fx, e, dt)}
     if rank == 0:
         if sub:
