@@ -127,3 +127,25 @@ def test_resnet50_pyramid_equals_hf_resnet():
     assert float((feats[0] - stem).abs().max()) <= 1e-5 * float(stem.abs().max())
     for f, hs in zip(feats[1:], out.hidden_states[1:]):
         assert f.shape == hs.shape and float((f - hs).abs().max()) <= 1e-4 * float(hs.abs().max())
+
+
+def test_cfanet_encoder_block_equals_torch_transformer_encoder_layer():
+    """The CFANet head has no independent implementation to lean on here (pyiqa absent, transformers has no CFANet). Its self-attention
+    block, though, is the textbook pre-norm encoder layer: the oracle's EncoderLayer (oracle/topiq.py, pyiqa key names) must equal
+    torch's own nn.TransformerEncoderLayer(norm_first=True, activation='gelu') on the same weights - a second opinion on the order of
+    norm / attention / residual / MLP, which a checkpoint cannot reveal (these choices carry no parameters)."""
+    import torch.nn as nn
+    from oracle.topiq import EncoderLayer
+    d, heads, ff, L, B = 64, 4, 256, 19, 3
+    ours = EncoderLayer(d, heads, ff).eval()
+    g = torch.Generator().manual_seed(3)
+    for p in ours.parameters():
+        p.data = torch.randn(p.shape, generator=g) * 0.1
+    ref = nn.TransformerEncoderLayer(d, heads, dim_feedforward=ff, dropout=0.0, activation="gelu", norm_first=True).eval()
+    sd = ours.state_dict()
+    ref.load_state_dict({k: sd[k] for k in ref.state_dict()})          # identical key names: self_attn.*, linear1/2.*, norm1/2.*
+    x = torch.randn(L, B, d, generator=g)
+    with torch.no_grad():
+        a = ours(x)
+        b = ref(x)
+    assert float((a - b).abs().max()) < 1e-5
