@@ -247,3 +247,41 @@ def test_clip_in_bf16_beside_fp32_models_in_one_context(eng16, engine):
         assert np.array_equal(rm[:, 1], r16[:, 1]) and np.array_equal(rm[:, 21:], r16[:, 21:])        # aesthetic, embedding: the bf16 tower
     finally:
         mixed.close()
+
+
+@pytest.mark.parametrize("hw", [(97, 131), (33, 500), (64, 64)])
+def test_topiq_bf16_arbitrary_sizes(eng16, hw):
+    """The edge cases of tests/test_edge_cases_gpu.py on the bf16 path: sizes that are not multiples of 32 (ceil-mode pyramid, ragged
+    adaptive pooling windows, odd token grids, ragged stem tiles), against the fp32 oracle at the bf16 tolerance."""
+    from oracle.topiq import CFANet
+    sd = _load(eng16, ["topiq"], 3)["topiq"]
+    net = CFANet().eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    imgs = synthetic_images(21, 2, *hw)
+    with torch.no_grad():
+        ref = net(torch.from_numpy(imgs.astype(np.float32) / 255).permute(0, 3, 1, 2)).flatten().numpy()
+    eng16.set_microbatch(8)
+    got = eng16.topiq_score(imgs)
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
+    print(f"[bf16 topiq {hw}] {got} vs {ref}: rel {rel}")
+    assert rel.max() < 2e-2
+
+
+def test_bf16_single_image_microbatch_and_long_edge_cap(eng16):
+    """Micro-batch larger than the batch / of one image give the same scores up to the row-count-dependent tile choices; an image with a
+    long edge > 1024 is LANCZOS-reduced on the GPU exactly as PyIQAScorer._preprocess_image does with PIL on the host
+    (models/pyiqa_scorer.py:131-153) - that stage is precision-independent, so engine(big) == engine(PIL-resized) bit for bit."""
+    from PIL import Image
+    _load(eng16, ["topiq"], 3)
+    imgs = synthetic_images(22, 3, 96, 96)
+    eng16.set_microbatch(64)
+    a = eng16.topiq_score(imgs)
+    eng16.set_microbatch(1)
+    b = eng16.topiq_score(imgs)
+    one = eng16.topiq_score(imgs[1:2])
+    assert np.allclose(a, b, rtol=2e-2) and np.allclose(one, a[1:2], rtol=2e-2)
+    big = synthetic_images(31, 2, 700, 1400)
+    scale = 1024 / 1400
+    small = np.stack([np.asarray(Image.fromarray(x).resize((int(1400 * scale), int(700 * scale)), Image.LANCZOS)) for x in big])
+    eng16.set_microbatch(2)
+    assert np.array_equal(eng16.topiq_score(big), eng16.topiq_score(small))
