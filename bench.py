@@ -39,35 +39,49 @@ METRIC = "images/sec whole-node (TOPIQ+SAMP+CLIP+InsightFace ensemble), 1024² b
 FACES_PER_IMAGE = 2
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: bf16 MFMA dense peak (~2.5 PF; the 5 PF headline includes 2:1 sparsity)
+TRAFFIC_FILE = "r03_traffic.json"   # written by tools/traffic_all.sh + tools/collect_traffic.py from this round's --pmc passes
 WORKLOADS = ["full", "topiq", "topiq_clip", "ensemble", "faces"]
 # which models a workload runs: ensemble mask (1 topiq | 2 clip | 4 samp) and whether the face stage runs
 WL = {"topiq": (1, False), "topiq_clip": (3, False), "ensemble": (7, False), "faces": (5, True), "full": (7, True)}
 
 
+HALF_NOTE = {
+    "bf16": "bf16 (bf16 activations / weights, fp32 accumulate; fp32 only: CLIP's 14x14 patch embedding, non-7x7 first layers, LayerNorm / "
+            "softmax statistics, score heads)",
+    "f16": "fp16 (fp16 activations / weights, fp32 accumulate; fp32 only: CLIP's 14x14 patch embedding, non-7x7 first layers, LayerNorm / "
+           "softmax statistics, score heads)",
+}
+FACE_TEXT = (f"InsightFace-style SCRFD detect @640 + 2d106 landmarks + ArcFace-R50 ({FACES_PER_IMAGE} best faces/image, seeded "
+             "stand-in ONNX graphs of the buffalo_l architectures)")
+
+
+def policy_text(policy):
+    """Human-readable precision of a per-model policy dict {'topiq','clip','samp'} -> 'f32' | 'bf16' | 'f16' (+ '+r32')."""
+    return ", ".join(f"{k} {v}" for k, v in policy.items())
+
+
 def workload_text(wl, B, HW, dtype="f32"):
-    t = _workload_text(wl, B, HW)
-    if dtype == "clip_bf16":
-        return t.replace("CLIP ViT-L/14 + aesthetic MLP", "CLIP ViT-L/14 in bf16 (the reference halves CLIP on a GPU, processing/scorer.py:513-516; "
-                         "aesthetic MLP fp32 on the fp32 features as there)")
-    if dtype == "bf16":
-        t = t.replace(" fp32", " bf16 (bf16 activations / weights, fp32 accumulate, fp32 first layers + LayerNorm / softmax statistics + score heads)")
-        if wl == "ensemble":
-            t = t.replace("(no InsightFace; the fp32 form of BASELINE configs[3])", "(BASELINE configs[3]: the 16gb profile in bf16)")
-    return t
-
-
-def _workload_text(wl, B, HW):
-    face = (f"InsightFace-style SCRFD detect @640 + 2d106 landmarks + ArcFace-R50 ({FACES_PER_IMAGE} best faces/image, seeded "
-            "stand-in ONNX graphs of the buffalo_l architectures)")
+    """One sentence naming the workload and its arithmetic. dtype: 'f32', 'bf16', 'f16' (all three models of the ensemble in that
+    type), 'clip_f16' / 'clip_bf16' (the reference's own GPU precisions: CLIP halved, processing/scorer.py:513-516, the rest fp32) or
+    'policy' (the per-model policy of DESIGN.md 4c, spelled out in config.precision)."""
+    clip = "CLIP ViT-L/14 + aesthetic MLP"
+    prec = "fp32"
+    if dtype in ("clip_f16", "clip_bf16"):
+        h = "fp16" if dtype == "clip_f16" else "bf16"
+        clip = (f"CLIP ViT-L/14 in {h} (the reference halves CLIP on a GPU, processing/scorer.py:513-516; aesthetic MLP fp32 on the fp32 "
+                "features as there)")
+    elif dtype in HALF_NOTE:
+        prec = HALF_NOTE[dtype]
+    elif dtype == "policy":
+        prec = "per-model precision policy (config.precision)"
+    cfg3 = "BASELINE configs[3]: the 16gb profile" if dtype in HALF_NOTE or dtype == "policy" else "no InsightFace; the fp32 form of BASELINE configs[3]"
     return {
-        "topiq": f"TOPIQ-NR (ResNet-50 pyramid + CFANet head) fp32, batch {B}/GPU, {HW}x{HW} RGB (BASELINE.json configs[1])",
-        "faces": f"TOPIQ + SAMP-Net/U2-Net-P + {face} fp32, batch {B}/GPU, {HW}x{HW} (BASELINE.json configs[2])",
-        "full": f"whole ensemble of the metric: TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP + {face} fp32, "
-                f"batch {B}/GPU, {HW}x{HW}",
-        "topiq_clip": f"TOPIQ-NR + CLIP ViT-L/14 image tower + aesthetic MLP fp32 (north_star's 'TOPIQ+CLIP forward'), "
+        "topiq": f"TOPIQ-NR (ResNet-50 pyramid + CFANet head) {prec}, batch {B}/GPU, {HW}x{HW} RGB (BASELINE.json configs[1])",
+        "faces": f"TOPIQ + SAMP-Net/U2-Net-P + {FACE_TEXT} {prec}, batch {B}/GPU, {HW}x{HW} (BASELINE.json configs[2])",
+        "full": f"whole ensemble of the metric: TOPIQ + SAMP-Net/U2-Net-P + {clip} + {FACE_TEXT} {prec}, batch {B}/GPU, {HW}x{HW}",
+        "topiq_clip": f"TOPIQ-NR + CLIP ViT-L/14 image tower + aesthetic MLP {prec} (north_star's 'TOPIQ+CLIP forward'), "
                       f"batch {B}/GPU, {HW}x{HW} RGB",
-        "ensemble": f"TOPIQ + SAMP-Net/U2-Net-P + CLIP ViT-L/14 + aesthetic MLP fp32 (no InsightFace; the fp32 form of BASELINE "
-                    f"configs[3]), batch {B}/GPU, {HW}x{HW} RGB",
+        "ensemble": f"TOPIQ + SAMP-Net/U2-Net-P + {clip} {prec} ({cfg3}), batch {B}/GPU, {HW}x{HW} RGB",
     }[wl]
 
 
@@ -82,6 +96,9 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
                             net.eval())[1]
     net = ld(CFANet(), "topiq")
     imgs = synthetic_images(2, sample, hw, hw)
+    # the whole host, whatever share of it the launcher gave this rank's OpenMP pool (self_launch sets OMP_NUM_THREADS = cpus / N
+    # for the ranks' own host glue): the baseline at N > 1 is the same measurement as at N = 1
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
     cores = torch.get_num_threads()
     extras = []
     if workload in ("faces", "full"):
@@ -169,12 +186,12 @@ def traffic_bytes(workload, HW, B):
     """HBM traffic of the workload from the PMC passes (profiles/rNN_traffic.json; collected with rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this script; gfx950 correction: FETCH_SIZE counts 64 B per 128-B request, so it is doubled -
     /opt/skills/guides/MI355X_MICROARCH.md, HBM section). Bytes per STEP of one GPU, or None when that workload was not collected."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            tj = json.load(open(path)).get(workload)
-            if tj and tj.get("image_size") == HW:
-                return int((2.0 * tj["fetch_kb_per_image"] + tj["write_kb_per_image"]) * 1024 * B), name
+    name = TRAFFIC_FILE      # this round's passes only: bytes measured on older kernels are never attached to this round's timings
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        tj = json.load(open(path)).get(workload)
+        if tj and tj.get("image_size") == HW:
+            return int((2.0 * tj["fetch_kb_per_image"] + tj["write_kb_per_image"]) * 1024 * B), name
     return None, None
 
 

@@ -22,7 +22,10 @@ FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC = 0, 1, 2
 FE_FACE_FLOATS = 739
 FE_STATS_DOUBLES = 264
 FILTERS = {"lanczos": 1, "bilinear": 2, "bicubic": 3}
-PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+FE_PRECISION_RES32 = 16      # or-ed onto a 2-byte precision: fp32 residual streams (include/facet_engine.h fe_precision)
+PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2, "half": 2,
+             "bf16+r32": 1 | FE_PRECISION_RES32, "f16+r32": 2 | FE_PRECISION_RES32}
+PRECISION_NAME = {0: "f32", 1: "bf16", 2: "f16", 1 | FE_PRECISION_RES32: "bf16+r32", 2 | FE_PRECISION_RES32: "f16+r32"}
 ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3, "softplus": 5}
 
 
@@ -220,13 +223,14 @@ class Engine:
         self._ck(self.lib.fe_sync(self.h))
 
     def set_precision(self, precision):
-        """'f32' (default, the reference's CPU numerics) or 'bf16' (BASELINE configs[3]) for the models loaded AFTER this call."""
+        """Precision of the models loaded AFTER this call: 'f32' (default, the reference's CPU numerics), 'f16' (what the reference
+        runs CLIP in on a GPU), 'bf16' (BASELINE configs[3]); '+r32' keeps the residual streams in fp32 ('f16+r32', 'bf16+r32')."""
         self._ck(self.lib.fe_set_precision(self.h, PRECISION[precision]))
 
     def model_precision(self, model):
-        """'f32' / 'bf16' of a loaded model, None when it is not loaded."""
+        """'f32' / 'f16' / 'bf16' (+ '+r32') of a loaded model, None when it is not loaded."""
         v = self.lib.fe_model_precision(self.h, int(model))
-        return {0: "f32", 1: "bf16"}.get(v)
+        return PRECISION_NAME.get(v)
 
     def set_microbatch(self, n):
         self._ck(self.lib.fe_set_microbatch(self.h, int(n)))
@@ -499,6 +503,7 @@ class Engine:
     def ensemble_select(self, models=7):
         """Which loaded models ensemble_score runs: 1 topiq | 2 clip (+ aesthetic) | 4 samp."""
         self._ck(self.lib.fe_ensemble_select(self.h, int(models)))
+        self.ensemble_mask = int(models)
 
     def ensemble_score_dev(self, images, d_records, ld_records=FE_RECORD_FLOATS):
         """ensemble_score with the [n, ld_records] float32 records left in device memory at `d_records` (an int address or

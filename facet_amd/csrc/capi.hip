@@ -290,17 +290,21 @@ int fe_weights_set(fe_ctx* ctx, int model, const char* name, const float* data, 
 }
 int fe_set_precision(fe_ctx* ctx, int precision) {
   FE_API_BEGIN(ctx)
-  FE_CHECK(precision == FE_PRECISION_F32 || precision == FE_PRECISION_BF16, "set_precision: %d", precision);
+  const int base = precision & ~FE_PRECISION_RES32;
+  FE_CHECK(base == FE_PRECISION_F32 || base == FE_PRECISION_BF16 || base == FE_PRECISION_F16, "set_precision: %d", precision);
+  FE_CHECK(base != FE_PRECISION_F32 || !(precision & FE_PRECISION_RES32), "set_precision: FE_PRECISION_RES32 qualifies a 2-byte precision");
   std::lock_guard<std::mutex> lk(ctx->c.mu);
-  ctx->c.precision = precision;
+  ctx->c.precision = base;
+  ctx->c.res32 = (precision & FE_PRECISION_RES32) != 0;
   FE_API_END(ctx)
 }
 int fe_model_precision(fe_ctx* ctx, int model) {
   if (!ctx) return -1;
-  if (model == FE_MODEL_TOPIQ && ctx->c.topiq) return ctx->c.topiq->dw.prec;
-  if (model == FE_MODEL_U2NETP && ctx->c.u2netp) return ctx->c.u2netp->dw.prec;
-  if (model == FE_MODEL_SAMP && ctx->c.samp) return ctx->c.samp->dw.prec;
-  if (model == FE_MODEL_CLIP && ctx->c.clip) return ctx->c.clip->dw.prec;
+  auto code = [](const DeviceWeights& dw) { return dw.prec | (dw.res32 ? FE_PRECISION_RES32 : 0); };
+  if (model == FE_MODEL_TOPIQ && ctx->c.topiq) return code(ctx->c.topiq->dw);
+  if (model == FE_MODEL_U2NETP && ctx->c.u2netp) return code(ctx->c.u2netp->dw);
+  if (model == FE_MODEL_SAMP && ctx->c.samp) return code(ctx->c.samp->dw);
+  if (model == FE_MODEL_CLIP && ctx->c.clip) return code(ctx->c.clip->dw);
   if (model == FE_MODEL_AESTHETIC && ctx->c.aesthetic) return FE_PRECISION_F32;
   return -1;
 }
@@ -323,7 +327,7 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
   WeightStore& ws = ctx->c.staging[model];
   if (model == FE_MODEL_TOPIQ) {
     auto m = std::make_unique<TopiqModel>();
-    m->dw.prec = ctx->c.precision;
+    m->dw.prec = ctx->c.precision; m->dw.res32 = ctx->c.res32;
     m->gate_act = ctx->c.topiq_gate_act;
     m->wblk_act = ctx->c.topiq_wblk_act;
     const int blocks[4] = {3, 4, 6, 3};
@@ -332,12 +336,12 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
     ctx->c.topiq = std::move(m);
   } else if (model == FE_MODEL_U2NETP) {
     auto m = std::make_unique<U2NetPModel>();
-    m->dw.prec = ctx->c.precision;
+    m->dw.prec = ctx->c.precision; m->dw.res32 = ctx->c.res32;
     build_u2netp(*m, ws);
     ctx->c.u2netp = std::move(m);
   } else if (model == FE_MODEL_CLIP) {
     auto m = std::make_unique<ClipModel>();
-    m->dw.prec = ctx->c.precision;      // the image tower; the text tower (built below, run once per vocabulary) stays fp32
+    m->dw.prec = ctx->c.precision; m->dw.res32 = ctx->c.res32;      // the image tower; the text tower (built below, run once per vocabulary) stays fp32
     build_clip(*m, ws);
     ctx->c.clip = std::move(m);
     if (ws.has("token_embedding.weight")) {   // full CLIP checkpoint: also build the text tower
@@ -353,7 +357,7 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
     ctx->c.aesthetic = std::move(m);
   } else if (model == FE_MODEL_SAMP) {
     auto m = std::make_unique<SampModel>();
-    m->dw.prec = ctx->c.precision;
+    m->dw.prec = ctx->c.precision; m->dw.res32 = ctx->c.res32;
     build_sampnet(*m, ws);
     ctx->c.samp = std::move(m);
   } else {
@@ -530,15 +534,21 @@ int fe_op_conv2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, const 
   if (shift) { v.assign(shift, shift + cout); cw.shift = dw.upload(v); }
   const int ho = conv_out_dim(h, kh, stride, pad, dil), wo = conv_out_dim(w, kw, stride, pad, dil);
   FE_CHECK(ho > 0 && wo > 0, "conv output is empty");
-  if (C.precision == PREC_BF16) {
-    FE_CHECK(cw.wh, "fe_op_conv2d(bf16): Cin must be a multiple of 8 (16 for spatial kernels)");
-    TensorH xt = upload_nchw<bf16>(C, x, n, c, h, w, cw.CinPadH);
-    ConvOptsT<bf16> o;
+  auto half_op = [&](auto* tag) {      // the same op on the 2-byte kernel (inputs rounded on upload, fp32 back)
+    typedef std::remove_pointer_t<decltype(tag)> E;
+    FE_CHECK(cw.wh, "fe_op_conv2d(2-byte): Cin must be a multiple of 8 (16 for spatial kernels)");
+    TensorT<E> xt = upload_nchw<E>(C, x, n, c, h, w, cw.CinPadH);
+    ConvOptsT<E> o;
     o.sh = o.sw = stride; o.ph = o.pw = pad; o.dh = o.dw = dil; o.act = act; o.res_after_act = res_after_act;
-    TensorH rt;
-    if (res) { rt = upload_nchw<bf16>(C, res, n, cout, ho, wo, cout); o.res = &rt; }
-    TensorH yt = conv_new(C, cw, xt, o);
+    TensorT<E> rt;
+    if (res) { rt = upload_nchw<E>(C, res, n, cout, ho, wo, cout); o.res = &rt; }
+    TensorT<E> yt = conv_new(C, cw, xt, o);
     download_nchw(C, yt, cout, y);
+  };
+  if (C.precision == PREC_BF16) {
+    half_op((bf16*)nullptr);
+  } else if (C.precision == PREC_F16) {
+    half_op((f16*)nullptr);
   } else {
     Tensor xt = upload_nchw(C, x, n, c, h, w, cw.CinPad);
     ConvOpts o;
@@ -680,6 +690,10 @@ static void topiq_chunk_score(fe_ctx* ctx, const uint8_t* d_in, int nb, int h, i
     std::vector<TensorH> feats;
     topiq_backbone_chunk<bf16>(ctx, d_in, nb, h, w, feats);
     topiq_head_forward<bf16>(C, *C.topiq, feats, d_scores);
+  } else if (C.topiq->dw.prec == PREC_F16) {
+    std::vector<TensorF16> feats;
+    topiq_backbone_chunk<f16>(ctx, d_in, nb, h, w, feats);
+    topiq_head_forward<f16>(C, *C.topiq, feats, d_scores);
   } else {
     std::vector<Tensor> feats;
     topiq_backbone_chunk<float>(ctx, d_in, nb, h, w, feats);
@@ -727,6 +741,12 @@ int fe_topiq_features(fe_ctx* ctx, const uint8_t* rgb, int n, int h, int w, int 
       const TensorH& f = feats[level];
       out_per_img = (size_t)f.c * f.h * f.w;
       download_nchw(C, f, f.c, out + (size_t)i0 * out_per_img);
+    } else if (C.topiq->dw.prec == PREC_F16) {
+      std::vector<TensorF16> feats;
+      topiq_backbone_chunk<f16>(ctx, d_in, nb, h, w, feats);
+      const TensorF16& f = feats[level];
+      out_per_img = (size_t)f.c * f.h * f.w;
+      download_nchw(C, f, f.c, out + (size_t)i0 * out_per_img);
     } else {
       std::vector<Tensor> feats;
       topiq_backbone_chunk<float>(ctx, d_in, nb, h, w, feats);
@@ -767,12 +787,17 @@ extern "C++" {
 // committed under. d_sal (nullable): fp32 device [n][h][w] copy of the saliency map.
 static void samp_chunk(fe_ctx* ctx, const Tensor& x, bool with_samp, float* pw, float* at, float* sd, float* d_sal) {
   Ctx& C = ctx->c;
-  const bool half = C.u2netp->dw.prec == PREC_BF16;
-  FE_CHECK(!with_samp || (C.samp->dw.prec == PREC_BF16) == half, "u2netp and samp_net were committed under different precisions");
-  if (half) {
+  const int prec = C.u2netp->dw.prec;
+  FE_CHECK(!with_samp || C.samp->dw.prec == prec, "u2netp and samp_net were committed under different precisions");
+  if (prec == PREC_BF16) {
     TensorH sal = C.arena.tensor_t<bf16>(x.n, x.h, x.w, 1);
     u2netp_forward<bf16>(C, *C.u2netp, x, sal);
     if (with_samp) sampnet_forward<bf16>(C, *C.samp, x, sal, pw, at, sd);
+    if (d_sal) launch_convert(sal.p, d_sal, sal.numel(), C.stream);
+  } else if (prec == PREC_F16) {
+    TensorF16 sal = C.arena.tensor_t<f16>(x.n, x.h, x.w, 1);
+    u2netp_forward<f16>(C, *C.u2netp, x, sal);
+    if (with_samp) sampnet_forward<f16>(C, *C.samp, x, sal, pw, at, sd);
     if (d_sal) launch_convert(sal.p, d_sal, sal.numel(), C.stream);
   } else {
     Tensor sal = C.arena.tensor(x.n, x.h, x.w, 1);
@@ -860,6 +885,7 @@ static int clip_tower_chunk(const ClipModel& m, int n) {
 }
 static void clip_tower(Ctx& C, const Tensor& x, float* feat) {   // in the precision the tower was committed under
   if (C.clip->dw.prec == PREC_BF16) clip_forward<bf16>(C, *C.clip, x, feat);
+  else if (C.clip->dw.prec == PREC_F16) clip_forward<f16>(C, *C.clip, x, feat);
   else clip_forward<float>(C, *C.clip, x, feat);
 }
 class ClipBatcher {

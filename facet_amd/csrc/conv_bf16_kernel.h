@@ -28,20 +28,20 @@ namespace fe {
 
 typedef float h_f32x16 __attribute__((ext_vector_type(16)));
 typedef float h_v4f __attribute__((ext_vector_type(4)));
-typedef __bf16 h_bf8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* h_lptr_t;
 
 union H8 {            // 16 bytes: one DMA chunk / one MFMA fragment / one epilogue store
   h_v4f f;
-  h_bf8 b;
   uint4 u;
 };
 
+// E below = the 2-byte element type of a launch: bf16 or f16 (fe_common.h: fe_mfma16 / fe_unpack2 / fe_pack2 overloads). Everything
+// but the matrix instruction and the conversions at the edges of the epilogue is the same code.
+template <class E>
 __device__ __forceinline__ void h_unpack8(const uint4 u, float v[8]) {
-  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
-  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
-  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xFFFF0000u);
-  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xFFFF0000u);
+  const E* tag = nullptr;
+  fe_unpack2(tag, u.x, v[0], v[1]); fe_unpack2(tag, u.y, v[2], v[3]);
+  fe_unpack2(tag, u.z, v[4], v[5]); fe_unpack2(tag, u.w, v[6], v[7]);
 }
 
 
@@ -60,8 +60,8 @@ __device__ __forceinline__ void h_unpack8(const uint4 u, float v[8]) {
 typedef unsigned h_v2u __attribute__((ext_vector_type(2)));
 typedef unsigned h_v4u __attribute__((ext_vector_type(4)));
 typedef float h_v4 __attribute__((ext_vector_type(4)));
-template <int TM, int TN, int ACTK, bool RES, bool GATE>
-__device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const ConvParamsH& p, const int row0, const int col0,
+template <class E, int TM, int TN, int ACTK, bool RES, bool GATE>
+__device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const ConvParamsT<E>& p, const int row0, const int col0,
                                                 const int lane, char* const stage) {
   constexpr unsigned OOB = 0xFFFFFFF0u;
   constexpr int PITCH = TN * 64 + 16;          // bytes per staged row: TN * 32 bf16 + 16 (conflict-free 8-byte writes, 16-byte aligned reads)
@@ -71,8 +71,8 @@ __device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const C
   const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
   const bool hs = p.scale != nullptr, hb = p.shift != nullptr;
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_span, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(RES ? p.res : p.y), 0, RES ? (int)p.r_span : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(GATE ? p.gate : p.y), 0, GATE ? (int)p.g_span : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<E*>(RES ? p.res : p.y), 0, RES ? (int)p.r_span : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<E*>(GATE ? p.gate : p.y), 0, GATE ? (int)p.g_span : 0, 0x00020000);
   // a null scale / shift becomes an empty buffer: every read returns 0
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hs ? p.scale : p.shift), 0, hs ? p.Cout * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb ? p.shift : p.scale), 0, hb ? p.Cout * 4 : 0, 0x00020000);
@@ -115,26 +115,26 @@ __device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const C
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        float v[4];
+        float v[4], rf4[4] = {0.f, 0.f, 0.f, 0.f}, gf4[4] = {1.f, 1.f, 1.f, 1.f};
+        if (RES) { fe_unpack2((const E*)nullptr, ru[i].x, rf4[0], rf4[1]); fe_unpack2((const E*)nullptr, ru[i].y, rf4[2], rf4[3]); }
+        if (GATE) { fe_unpack2((const E*)nullptr, gu[i].x, gf4[0], gf4[1]); fe_unpack2((const E*)nullptr, gu[i].y, gf4[2], gf4[3]); }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = acc[i][j][4 * g + e] * s4[e] + b4[e];
-          float rf = 0.f;
-          if (RES) rf = __uint_as_float((e & 1) ? ((e < 2 ? ru[i].x : ru[i].y) & 0xFFFF0000u) : ((e < 2 ? ru[i].x : ru[i].y) << 16));
+          const float rf = rf4[e];
           if (RES && !p.res_after_act) x += rf;
           if (ACTK == 1) x = x > 0.f ? x : 0.f;
           else if (ACTK == 2) x = fe_gelu_fast(x);
           else if (ACTK == 3) x = __frcp_rn(1.f + __expf(-x));
           else if (ACTK < 0) x = fe_apply_act_fast(x, p.act);
           if (RES && p.res_after_act) x += rf;
-          if (GATE) x *= __uint_as_float((e & 1) ? ((e < 2 ? gu[i].x : gu[i].y) & 0xFFFF0000u) : ((e < 2 ? gu[i].x : gu[i].y) << 16));
+          if (GATE) x *= gf4[e];
           if (ACTK < 0 || ACTK == 3) x = (c0 + e < p.Cout) ? x : 0.f;      // sigmoid(0) != 0: keep the padded columns zero
           v[e] = x;
         }
-        union { bf16 b[4]; h_v2u u; } o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o.b[e] = (bf16)v[e];
-        *reinterpret_cast<h_v2u*>(stage + (32 * i + r) * PITCH + (32 * j + 8 * g + 4 * h) * 2) = o.u;
+        h_v2u o;
+        o.x = fe_pack2((const E*)nullptr, v[0], v[1]); o.y = fe_pack2((const E*)nullptr, v[2], v[3]);
+        *reinterpret_cast<h_v2u*>(stage + (32 * i + r) * PITCH + (32 * j + 8 * g + 4 * h) * 2) = o;
       }
     }
   }
@@ -152,8 +152,8 @@ __device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const C
 
 // UNITS = 32 / cb: (channel block, tap) units per 32-element slab. MODE 0 plain, 2 PReLU epilogue.
 // ONE_TAP: 1x1 kernels (GEMMs) - no tap masks, the K offset of a slab goes into the scalar offset of the buffer load.
-template <int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
-__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM * 32 % 64 == 0 && WGN * TN * 32 % 64 == 0 ? 3 : 2) : 3)))) void conv_bf16_kernel(ConvParamsH p, const int ntiles, const int ntotal) {
+template <class E, int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM * 32 % 64 == 0 && WGN * TN * 32 % 64 == 0 ? 3 : 2) : 3)))) void conv_bf16_kernel(ConvParamsT<E> p, const int ntiles, const int ntotal) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int NW = WGM * WGN;                              // waves per workgroup: 4, or 8 for the 256x256 tile
   constexpr int AI = (BM + 16 * NW - 1) / (16 * NW), BI = (BN + 16 * NW - 1) / (16 * NW);    // DMA pieces per wave per slab (16 rows x 64 B each)
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
     }
   };
   setup_tile(blockIdx.x);
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.x), 0, (int)p.x_span, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.w), 0, (int)p.w_span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<E*>(p.x), 0, (int)p.x_span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<E*>(p.w), 0, (int)p.w_span, 0x00020000);
 
   // block-uniform running state of the next unit(s) to fetch: unit u -> channel block u / ntaps, tap u % ntaps
   const int CB = 32 / UNITS;
@@ -287,19 +287,19 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
       // form that reads activation, gate and residual order from the parameters
       const bool plain = !p.gate && !(p.res && p.res_after_act);
       if (plain && p.act == ACT_NONE) {
-        if (p.res) h_epilogue_wide<TM, TN, 0, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 0, false, false>(acc, p, row0, col0, lane, stage);
+        if (p.res) h_epilogue_wide<E, TM, TN, 0, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<E, TM, TN, 0, false, false>(acc, p, row0, col0, lane, stage);
       } else if (plain && p.act == ACT_RELU) {
-        if (p.res) h_epilogue_wide<TM, TN, 1, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 1, false, false>(acc, p, row0, col0, lane, stage);
+        if (p.res) h_epilogue_wide<E, TM, TN, 1, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<E, TM, TN, 1, false, false>(acc, p, row0, col0, lane, stage);
       } else if (plain && p.act == ACT_GELU) {
-        if (p.res) h_epilogue_wide<TM, TN, 2, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, 2, false, false>(acc, p, row0, col0, lane, stage);
+        if (p.res) h_epilogue_wide<E, TM, TN, 2, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<E, TM, TN, 2, false, false>(acc, p, row0, col0, lane, stage);
       } else if (plain && p.act == ACT_SIGMOID && !p.res) {
-        h_epilogue_wide<TM, TN, 3, false, false>(acc, p, row0, col0, lane, stage);
+        h_epilogue_wide<E, TM, TN, 3, false, false>(acc, p, row0, col0, lane, stage);
       } else if (p.gate && !p.res && p.act == ACT_GELU) {
-        h_epilogue_wide<TM, TN, 2, false, true>(acc, p, row0, col0, lane, stage);       // TOPIQ GatedConv, default gate activation
+        h_epilogue_wide<E, TM, TN, 2, false, true>(acc, p, row0, col0, lane, stage);       // TOPIQ GatedConv, default gate activation
       } else if (p.gate) {
-        if (p.res) h_epilogue_wide<TM, TN, -1, true, true>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, -1, false, true>(acc, p, row0, col0, lane, stage);
+        if (p.res) h_epilogue_wide<E, TM, TN, -1, true, true>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<E, TM, TN, -1, false, true>(acc, p, row0, col0, lane, stage);
       } else {
-        if (p.res) h_epilogue_wide<TM, TN, -1, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<TM, TN, -1, false, false>(acc, p, row0, col0, lane, stage);
+        if (p.res) h_epilogue_wide<E, TM, TN, -1, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<E, TM, TN, -1, false, false>(acc, p, row0, col0, lane, stage);
       }
     }
   };
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
       constexpr int hh_ = (Q) / (TM * TN), i_ = ((Q) / TN) % TM, j_ = (Q) % TN;                                         \
       H8 a_, b_;                                                                                                        \
       a_.f = fa[SET][2 * i_ + hh_]; b_.f = fb[SET][2 * j_ + hh_];                                                       \
-      if constexpr (TN > 1) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_.b, a_.b, acc[i_][j_], 0, 0, 0);  /* transposed tile */ \
-      else acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_.b, b_.b, acc[i_][j_], 0, 0, 0);                     \
+      if constexpr (TN > 1) acc[i_][j_] = fe_mfma16((const E*)nullptr, b_.f, a_.f, acc[i_][j_]);  /* transposed tile */      \
+      else acc[i_][j_] = fe_mfma16((const E*)nullptr, a_.f, b_.f, acc[i_][j_]);                                           \
     }
 #define FL_PIECE_AT(SLOT, N, Q)                                                                                          \
     if constexpr ((N) < NPW && (((N) + 1) * (2 * TM * TN) / (NPW + 1) - 1 < 0 ? 0 : ((N) + 1) * (2 * TM * TN) / (NPW + 1) - 1) == (Q)) { \
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
     float* smem = reinterpret_cast<float*>(smem_h);
     if (p.vec_epi) {
       constexpr int WC = TN * 32, ES = WC + 4, LPR = WC / 8, RPI = 64 / LPR, NIT = 32 / RPI;
-      float* E = smem + wave * 32 * ES;
+      float* Et = smem + wave * 32 * ES;
       const int lr = lane / LPR, lc = (lane % LPR) * 8;
       const int colb = n0 + wn * WC + lc;
       const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
   #pragma unroll
         for (int j = 0; j < TN; ++j)
   #pragma unroll
-          for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
+          for (int e = 0; e < 16; ++e) Et[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
         const int mrow0 = m0 + wm * TM * 32 + i * 32 + lr;
         uint4 rv[NIT];
         float gs[NIT];
@@ -531,12 +531,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
   #pragma unroll
         for (int it = 0; it < NIT; ++it) {
           const int m = mrow0 + it * RPI;
-          const float4 v0 = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc]);
-          const float4 v1 = *reinterpret_cast<const float4*>(&E[(lr + it * RPI) * ES + lc + 4]);
+          const float4 v0 = *reinterpret_cast<const float4*>(&Et[(lr + it * RPI) * ES + lc]);
+          const float4 v1 = *reinterpret_cast<const float4*>(&Et[(lr + it * RPI) * ES + lc + 4]);
           float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
           float rf[8], gf[8];
-          if (p.res) h_unpack8(rv[it], rf);
-          if (p.gate && !p.gate_c1) h_unpack8(gv[it], gf);
+          if (p.res) h_unpack8<E>(rv[it], rf);
+          if (p.gate && !p.gate_c1) h_unpack8<E>(gv[it], gf);
   #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float x = v[e] * sc[e] + sf[e];
@@ -549,8 +549,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
             v[e] = x;
           }
           H8 o;
-  #pragma unroll
-          for (int e = 0; e < 8; ++e) o.b[e] = (bf16)v[e];
+          o.u = make_uint4(fe_pack2((const E*)nullptr, v[0], v[1]), fe_pack2((const E*)nullptr, v[2], v[3]),
+                           fe_pack2((const E*)nullptr, v[4], v[5]), fe_pack2((const E*)nullptr, v[6], v[7]));
           if (cok && m < p.M) *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + colb) = o.u;
         }
       }
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
             else v = fe_apply_act(v, p.act);
             if (p.res && p.res_after_act) v += (float)p.res[(size_t)m * p.ldr + col];
             if (p.gate) v *= (float)p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
-            p.y[(size_t)m * p.ldy + col] = (bf16)v;
+            stf(&p.y[(size_t)m * p.ldy + col], v);
           }
         }
       }
@@ -586,15 +586,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
   }
 }
 
-template <int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
-void launch_bf16_variant(const ConvParamsH& p, hipStream_t s) {
+template <class E, int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
+void launch_bf16_variant(const ConvParamsT<E>& p, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
   constexpr size_t main_lds = (size_t)3 * (BM + BN) * 64 + (BN == 32 ? 4096 : 0);      // + the dummy pieces' scratch (32-column tiles)
   constexpr size_t epi_lds = TN > 1 ? (size_t)(WGM * WGN) * (TM * 32) * (TN * 64 + 16)      // wide tiles: bf16 image of every wave's tile
                                     : (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
-  auto kern = conv_bf16_kernel<WGM, WGN, TM, TN, UNITS, MODE, ONE_TAP>;
+  auto kern = conv_bf16_kernel<E, WGM, WGN, TM, TN, UNITS, MODE, ONE_TAP>;
   static std::atomic<uint64_t> lds_set{0};
   ensure_dynamic_lds((const void*)kern, lds, lds_set);
   const int ntotal = mtiles * ntiles;
@@ -604,13 +604,16 @@ void launch_bf16_variant(const ConvParamsH& p, hipStream_t s) {
 }
 
 
-// wide tiles (TN = 2): instantiated in kernels_conv_bf16_wide{1,2,3}.hip
-extern template void launch_bf16_variant<2, 2, 2, 2, 1, 0, true>(const ConvParamsH&, hipStream_t);
-extern template void launch_bf16_variant<2, 2, 4, 2, 1, 0, true>(const ConvParamsH&, hipStream_t);
-extern template void launch_bf16_variant<2, 2, 2, 2, 1, 0, false>(const ConvParamsH&, hipStream_t);
-extern template void launch_bf16_variant<2, 2, 4, 2, 1, 0, false>(const ConvParamsH&, hipStream_t);
-extern template void launch_bf16_variant<2, 2, 2, 2, 2, 0, false>(const ConvParamsH&, hipStream_t);
-extern template void launch_bf16_variant<2, 2, 4, 2, 2, 0, false>(const ConvParamsH&, hipStream_t);
-extern template void launch_bf16_variant<2, 4, 4, 2, 1, 0, true>(const ConvParamsH&, hipStream_t);     // 256x256, eight waves (kernels_conv_bf16_wide4.hip)
+// wide tiles (TN = 2): instantiated in kernels_conv_bf16_wide{1,2,3,4}.hip (bf16) and kernels_conv_f16_wide{1,2,3,4}.hip (f16)
+#define FE_WIDE_TILES(X, E)                                                                            \
+  X template void launch_bf16_variant<E, 2, 2, 2, 2, 1, 0, true>(const ConvParamsT<E>&, hipStream_t);  \
+  X template void launch_bf16_variant<E, 2, 2, 4, 2, 1, 0, true>(const ConvParamsT<E>&, hipStream_t);  \
+  X template void launch_bf16_variant<E, 2, 2, 2, 2, 1, 0, false>(const ConvParamsT<E>&, hipStream_t); \
+  X template void launch_bf16_variant<E, 2, 2, 4, 2, 1, 0, false>(const ConvParamsT<E>&, hipStream_t); \
+  X template void launch_bf16_variant<E, 2, 2, 2, 2, 2, 0, false>(const ConvParamsT<E>&, hipStream_t); \
+  X template void launch_bf16_variant<E, 2, 2, 4, 2, 2, 0, false>(const ConvParamsT<E>&, hipStream_t); \
+  X template void launch_bf16_variant<E, 2, 4, 4, 2, 1, 0, true>(const ConvParamsT<E>&, hipStream_t);      /* 256x256, eight waves */
+FE_WIDE_TILES(extern, bf16)
+FE_WIDE_TILES(extern, f16)
 
 }  // namespace fe

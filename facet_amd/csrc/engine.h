@@ -27,7 +27,8 @@ class WeightStore {
 // Owns device copies of packed weights for one model; freed together.
 class DeviceWeights {
  public:
-  int prec = 0;   // Precision the owning model is built for: pack_conv also emits the bf16 forms when PREC_BF16
+  int prec = 0;   // Precision the owning model is built for: pack_conv also emits the 2-byte forms (bf16 / f16) when it is not PREC_F32
+  bool res32 = false;   // FE_PRECISION_RES32: the model keeps its residual / skip streams in fp32 around 2-byte GEMM operands
   ~DeviceWeights() { release(); }
   float* upload(const std::vector<float>& v);
   void* upload_raw(const void* data, size_t bytes);   // any element type (bf16 weights)
@@ -47,13 +48,35 @@ struct LayerNormW {
 };
 
 // Precision of a model's activations / weights, chosen per context before fe_weights_commit (fe_set_precision).
-enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1 };
+enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
+constexpr int PREC_RES32_FLAG = 16;   // or-ed into fe_set_precision's argument (include/facet_engine.h FE_PRECISION_RES32)
+template <class T> struct PrecOf { static constexpr int value = PREC_F32; };
+template <> struct PrecOf<bf16> { static constexpr int value = PREC_BF16; };
+template <> struct PrecOf<f16> { static constexpr int value = PREC_F16; };
 // round-to-nearest-even float -> bf16 bits on the host (NaN stays NaN)
 inline uint16_t f32_to_bf16_bits(float f) {
   uint32_t u; memcpy(&u, &f, 4);
   if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
   return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
+// round-to-nearest-even float -> fp16 bits on the host, saturating at +-65504 like the device stores (NaN stays NaN)
+inline uint16_t f32_to_f16_bits(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  u &= 0x7FFFFFFFu;
+  if (u > 0x7F800000u) return (uint16_t)(sign | 0x7E00u);
+  if (u >= 0x477FF000u) return (uint16_t)(sign | 0x7BFFu);           // >= 65520 rounds past the largest finite value: saturate
+  if (u < 0x38800000u) {                                             // below 2^-14: subnormal half (or zero)
+    if (u < 0x33000000u) return (uint16_t)sign;                      // < 2^-25 rounds to zero
+    const int shift = 126 - (int)(u >> 23);                          // 14 .. 24
+    const uint32_t m = (u & 0x7FFFFFu) | 0x800000u;
+    const uint32_t h = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    return (uint16_t)(sign | (h + ((rem > half || (rem == half && (h & 1))) ? 1 : 0)));
+  }
+  const uint32_t h = ((u - 0x38000000u) >> 13), rem = u & 0x1FFFu;
+  return (uint16_t)(sign | (h + ((rem > 0x1000u || (rem == 0x1000u && (h & 1))) ? 1 : 0)));
+}
+inline uint16_t f32_to_half_bits(float f, int prec) { return prec == PREC_F16 ? f32_to_f16_bits(f) : f32_to_bf16_bits(f); }
 // Adds the bf16 forms (ConvW.wh / wtap_h) of a weight to an already packed ConvW; a no-op for layers the bf16 kernel cannot take
 // (3-channel first layers: those run on the fp32 stem / generic kernels and hand a bf16 tensor to the next layer).
 void pack_conv_bf16(DeviceWeights& dw, const HostTensor& w, ConvW& c);
@@ -77,7 +100,7 @@ struct Ctx;
 struct MHAW {
   ConvW q, k;          // projections with bias; q carries the 1/sqrt(head_dim) scaling in scale/shift
   float* wv = nullptr; // raw [d][d] V weight: used as the A operand so the GEMM emits V^T directly
-  bf16* wv_h = nullptr; // the same in bf16 (PREC_BF16 models)
+  void* wv_h = nullptr; // the same in the model's 2-byte type (bf16 / f16 models)
   float* bv = nullptr; // [d] V bias, added after P.V (softmax rows sum to 1)
   ConvW out;           // out_proj
   int d = 0, heads = 0;
@@ -94,9 +117,12 @@ void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, floa
                     const float* res = nullptr, int ldr = 0);
 void linear_forward(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16* y, int ldy, int act,
                     const bf16* res = nullptr, int ldr = 0);
+void linear_forward(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, f16* y, int ldy, int act,
+                    const f16* res = nullptr, int ldr = 0);
 // same with fp32 outputs whatever the activation type (the last layer of a head: scores / features leave the engine in fp32)
 void linear_forward_f32(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act);
 void linear_forward_f32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float* y, int ldy, int act);
+void linear_forward_f32(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, float* y, int ldy, int act);
 template <class T>
 inline TensorT<T> mat_view(const T* p, int rows, int cols, int ld) {
   TensorT<T> t; t.p = const_cast<T*>(p); t.n = 1; t.h = 1; t.w = rows; t.c = cols; t.ld = ld; return t;
@@ -105,6 +131,7 @@ inline TensorT<T> mat_view(const T* p, int rows, int cols, int ld) {
 // Runs conv on views; allocates nothing. Output spatial dims must already be set on y.
 void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, const ConvOpts& o);
 void conv_forward(Ctx& c, const ConvW& w, const TensorH& x, const TensorH& y, const ConvOptsT<bf16>& o);
+void conv_forward(Ctx& c, const ConvW& w, const TensorF16& x, const TensorF16& y, const ConvOptsT<f16>& o);
 // Allocates the output from the arena with the standard conv output size.
 template <class T>
 TensorT<T> conv_new(Ctx& c, const ConvW& w, const TensorT<T>& x, const ConvOptsT<T>& o);
@@ -159,6 +186,7 @@ struct Ctx {
   double flops_saved = 0.0;   // algorithmic FLOPs NOT executed because a layer ran as Winograd (executed = flops_accum - flops_saved)
   int force_variant = 0;   // developer hook: forwarded to ConvParams.variant
   int precision = PREC_F32;   // what the NEXT fe_weights_commit builds (fe_set_precision); each model remembers its own
+  bool res32 = false;         // FE_PRECISION_RES32 of the next commit: fp32 residual streams around 2-byte GEMM operands
   // TOPIQ GatedConv activations picked up by the next fe_weights_commit(FE_MODEL_TOPIQ) (fe_topiq_configure)
   int topiq_gate_act = ACT_GELU, topiq_wblk_act = ACT_GELU;
 
@@ -260,5 +288,6 @@ void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<TensorT<T>>& fe
 // fp32 view of an activation vector: the pointer itself for fp32, an arena copy for bf16
 inline const float* to_f32(Ctx&, const float* p, size_t) { return p; }
 const float* to_f32(Ctx& c, const bf16* p, size_t n);
+const float* to_f32(Ctx& c, const f16* p, size_t n);
 
 }  // namespace fe

@@ -47,6 +47,11 @@ const float* to_f32(Ctx& c, const bf16* p, size_t n) {
   launch_convert(p, f, n, c.stream);
   return f;
 }
+const float* to_f32(Ctx& c, const f16* p, size_t n) {
+  float* f = c.arena.array<float>(n);
+  launch_convert(p, f, n, c.stream);
+  return f;
+}
 
 Ctx::~Ctx() {
   topiq.reset();
@@ -131,11 +136,11 @@ ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>
   }
   if (scale) c.scale = dw.upload(*scale);
   if (shift) c.shift = dw.upload(*shift);
-  if (dw.prec == PREC_BF16) pack_conv_bf16(dw, w, c);
+  if (dw.prec != PREC_F32) pack_conv_bf16(dw, w, c);
   return c;
 }
 
-// bf16 form: [Cout][KpH], K order = channel block (cb) outer, tap inner, channel-in-block innermost (kernels_conv_bf16.hip);
+// 2-byte form (bf16 or f16, the precision of `dw`): [Cout][KpH], K order = channel block (cb) outer, tap inner, channel-in-block innermost (kernels_conv_bf16.hip);
 // 1x1 kernels keep plain channel order with Cin rounded up to 8 (the kernel zero-fills the chunk past Cin).
 void pack_conv_bf16(DeviceWeights& dw, const HostTensor& w, ConvW& c) {
   const int ntaps = c.KH * c.KW;
@@ -155,9 +160,10 @@ void pack_conv_bf16(DeviceWeights& dw, const HostTensor& w, ConvW& c) {
     for (int ci = 0; ci < c.Cin; ++ci)
       for (int t = 0; t < ntaps; ++t) {
         const size_t k = ntaps > 1 ? ((size_t)(ci / c.cb) * ntaps + t) * c.cb + (ci % c.cb) : (size_t)ci;
-        packed[(size_t)co * c.KpH + k] = f32_to_bf16_bits(w.data[((size_t)co * c.Cin + ci) * ntaps + t]);
+        packed[(size_t)co * c.KpH + k] = f32_to_half_bits(w.data[((size_t)co * c.Cin + ci) * ntaps + t], dw.prec);
       }
-  c.wh = (bf16*)dw.upload_raw(packed.data(), packed.size() * sizeof(uint16_t));
+  c.wh = dw.upload_raw(packed.data(), packed.size() * sizeof(uint16_t));
+  c.hprec = dw.prec;
   if (c.Cout <= 2 && ntaps > 1) {
     // tap-decomposed form (see pack_conv): rows (tap, co) of a 1x1 conv, row count rounded up to 8 for 16-byte stores
     const int T = ntaps * c.Cout, T8 = (T + 7) & ~7;
@@ -166,8 +172,8 @@ void pack_conv_bf16(DeviceWeights& dw, const HostTensor& w, ConvW& c) {
     for (int t = 0; t < ntaps; ++t)
       for (int co = 0; co < c.Cout; ++co)
         for (int ci = 0; ci < c.Cin; ++ci)
-          tp[(size_t)(t * c.Cout + co) * c.KpTH + ci] = f32_to_bf16_bits(w.data[((size_t)co * c.Cin + ci) * ntaps + t]);
-    c.wtap_h = (bf16*)dw.upload_raw(tp.data(), tp.size() * sizeof(uint16_t));
+          tp[(size_t)(t * c.Cout + co) * c.KpTH + ci] = f32_to_half_bits(w.data[((size_t)co * c.Cin + ci) * ntaps + t], dw.prec);
+    c.wtap_h = dw.upload_raw(tp.data(), tp.size() * sizeof(uint16_t));
   }
 }
 
@@ -399,8 +405,23 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
 // ---- bf16 path ------------------------------------------------------------------------------------------------------
 // Every dense layer goes to the bf16 MFMA kernel directly: no Winograd (F(4x4) needs more than 8 mantissa bits, and at the bf16
 // matrix rate the 3x3 layers are bound by their HBM streams, which the transforms would multiply), no split-K.
-void conv_forward(Ctx& c, const ConvW& w, const TensorH& x, const TensorH& y, const ConvOptsT<bf16>& o) {
-  FE_CHECK(w.wh, "conv(bf16): this layer has no bf16 weights (model not committed under bf16 precision, or a 3-channel first layer)");
+template <class E>
+static void conv_forward_half(Ctx& c, const ConvW& w, const TensorT<E>& x, const TensorT<E>& y, const ConvOptsT<E>& o) {
+  if (!w.wh && w.w && PrecOf<E>::value != PREC_F32 && !o.res && !o.gate && x.ld == x.c && y.ld == y.c && x.c >= w.CinPad) {
+    // A layer the 2-byte kernel has no form for (spatial kernels whose Cin rounded up to 8 is not a multiple of 16, or >= 64 taps):
+    // the fp32 kernel between two conversion passes, like the 3-channel first layers (first_conv_half). No model of the hot path
+    // has such a layer; a checkpoint variant that does still runs.
+    const size_t mark = c.arena.mark();
+    Tensor xf = c.arena.tensor(x.n, x.h, x.w, x.c), yf = c.arena.tensor(y.n, y.h, y.w, y.c);
+    launch_convert(x.p, xf.p, x.numel(), c.stream);
+    ConvOpts of; of.sh = o.sh; of.sw = o.sw; of.ph = o.ph; of.pw = o.pw; of.dh = o.dh; of.dw = o.dw; of.act = o.act;
+    conv_forward(c, w, xf.slice(0, w.CinPad), yf, of);
+    launch_convert(yf.p, y.p, y.numel(), c.stream);
+    c.arena.rewind(mark);
+    return;
+  }
+  FE_CHECK(w.wh && w.hprec == PrecOf<E>::value, "conv(2-byte): this layer has no weights of the activations' type (model committed under another "
+           "precision, or a 3-channel first layer)");
   FE_CHECK(x.c == w.CinPadH, "conv(bf16): input channels %d != packed Cin %d", x.c, w.CinPadH);
   FE_CHECK(y.c == w.Cout && y.n == x.n, "conv(bf16): output view mismatch (c=%d Cout=%d)", y.c, w.Cout);
   FE_CHECK(y.h == conv_out_dim(x.h, w.KH, o.sh, o.ph, o.dh) && y.w == conv_out_dim(x.w, w.KW, o.sw, o.pw, o.dw),
@@ -412,15 +433,15 @@ void conv_forward(Ctx& c, const ConvW& w, const TensorH& x, const TensorH& y, co
     FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
     FE_HIP(hipEventRecord(e0, c.stream));
   }
-  ConvParamsH p{};
+  ConvParamsT<E> p{};
   p.scale = w.scale; p.shift = w.shift; p.slope = w.slope;
   p.N = x.n; p.H = x.h; p.W = x.w; p.Cin = w.CinPadH; p.x = x.p; p.ldx = x.ld;
   if (w.wtap_h && o.act != ACT_PRELU && o.sh == 1 && o.sw == 1 && !o.res && !o.gate && y.h == x.h && y.w == x.w) {
     // narrow spatial conv (Cout <= 2): 1x1 conv to per-tap partials on the matrix cores + a gather-sum pass (see the fp32 path)
     const int T = w.KH * w.KW * w.Cout, T8 = (T + 7) & ~7;
     const size_t mark = c.arena.mark();
-    TensorH z = c.arena.tensor_t<bf16>(x.n, x.h, x.w, T8);
-    p.w = w.wtap_h; p.y = z.p; p.ldy = T8; p.scale = p.shift = p.slope = nullptr;
+    TensorT<E> z = c.arena.tensor_t<E>(x.n, x.h, x.w, T8);
+    p.w = (const E*)w.wtap_h; p.y = z.p; p.ldy = T8; p.scale = p.shift = p.slope = nullptr;
     p.Ho = x.h; p.Wo = x.w; p.Cout = T8; p.KH = p.KW = 1; p.sh = p.sw = p.dh = p.dw = 1;
     p.K = w.CinPadH; p.Kp = w.KpTH; p.M = (int)x.pixels(); p.cb = 32;
     launch_conv_bf16(p, c.stream);
@@ -436,7 +457,7 @@ void conv_forward(Ctx& c, const ConvW& w, const TensorH& x, const TensorH& y, co
       FE_CHECK(o.gate->pixels() == y.pixels() && (o.gate->c == 1 || o.gate->c == y.c), "conv: gate shape mismatch");
       p.gate = o.gate->p; p.ldg = o.gate->ld; p.gate_c1 = o.gate->c == 1;
     }
-    p.w = w.wh; p.y = y.p; p.ldy = y.ld;
+    p.w = (const E*)w.wh; p.y = y.p; p.ldy = y.ld;
     p.Ho = y.h; p.Wo = y.w; p.Cout = w.Cout;
     p.KH = w.KH; p.KW = w.KW; p.sh = o.sh; p.sw = o.sw; p.ph = o.ph; p.pw = o.pw; p.dh = o.dh; p.dw = o.dw;
     p.K = w.KH * w.KW * w.CinPadH; p.Kp = w.KpH; p.M = (int)y.pixels(); p.cb = w.cb;
@@ -451,12 +472,14 @@ void conv_forward(Ctx& c, const ConvW& w, const TensorH& x, const TensorH& y, co
     FE_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     char nm[128];
-    snprintf(nm, sizeof nm, "bf16 conv%dx%d s%d d%d M=%d K=%d N=%d", w.KH, w.KW, o.sh, o.dh, (int)y.pixels(), w.KH * w.KW * w.Cin, w.Cout);
+    snprintf(nm, sizeof nm, "%s conv%dx%d s%d d%d M=%d K=%d N=%d", PrecOf<E>::value == PREC_F16 ? "f16" : "bf16", w.KH, w.KW, o.sh, o.dh, (int)y.pixels(), w.KH * w.KW * w.Cin, w.Cout);
     const double bytes = 2.0 * ((double)x.pixels() * x.c + (double)y.pixels() * y.c * (o.res ? 2 : 1) + (double)w.Cout * w.KpH);
     c.timings.push_back({nm, flops, bytes, ms});
   }
   c.flops_accum += flops;
 }
+void conv_forward(Ctx& c, const ConvW& w, const TensorH& x, const TensorH& y, const ConvOptsT<bf16>& o) { conv_forward_half<bf16>(c, w, x, y, o); }
+void conv_forward(Ctx& c, const ConvW& w, const TensorF16& x, const TensorF16& y, const ConvOptsT<f16>& o) { conv_forward_half<f16>(c, w, x, y, o); }
 
 template <class T>
 TensorT<T> conv_new(Ctx& c, const ConvW& w, const TensorT<T>& x, const ConvOptsT<T>& o) {
@@ -466,13 +489,14 @@ TensorT<T> conv_new(Ctx& c, const ConvW& w, const TensorT<T>& x, const ConvOptsT
 }
 template Tensor conv_new<float>(Ctx&, const ConvW&, const Tensor&, const ConvOpts&);
 template TensorH conv_new<bf16>(Ctx&, const ConvW&, const TensorH&, const ConvOptsT<bf16>&);
+template TensorF16 conv_new<f16>(Ctx&, const ConvW&, const TensorF16&, const ConvOptsT<f16>&);
 
 template <>
 Tensor first_conv<float>(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o) { return conv_new(c, w, x, o); }
-template <>
-TensorH first_conv<bf16>(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o) {
+template <class E>
+static TensorT<E> first_conv_half(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o) {
   const int ho = conv_out_dim(x.h, w.KH, o.sh, o.ph, o.dh), wo = conv_out_dim(x.w, w.KW, o.sw, o.pw, o.dw);
-  TensorH y = c.arena.tensor_t<bf16>(x.n, ho, wo, w.Cout);
+  TensorT<E> y = c.arena.tensor_t<E>(x.n, ho, wo, w.Cout);
   static const bool no_stem = getenv("FE_NO_STEM") != nullptr;
   const bool stem = w.wstem && !no_stem && o.sh == o.sw && o.ph == w.KH / 2 && o.pw == w.KW / 2 && o.dh == 1 && o.dw == 1 && !o.res && !o.gate &&
                     (o.act == ACT_NONE || o.act == ACT_RELU || o.act == ACT_PRELU);
@@ -488,6 +512,10 @@ TensorH first_conv<bf16>(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts
   (void)mark;   // yf stays allocated until the caller's next rewind: y was taken from the arena before it
   return y;
 }
+template <>
+TensorH first_conv<bf16>(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o) { return first_conv_half<bf16>(c, w, x, o); }
+template <>
+TensorF16 first_conv<f16>(Ctx& c, const ConvW& w, const Tensor& x, const ConvOpts& o) { return first_conv_half<f16>(c, w, x, o); }
 
 // ---------------------------------------------------------------------------------------------------
 // ResNet
@@ -553,6 +581,7 @@ TensorT<T> resnet_forward(Ctx& c, const ResNet& r, const Tensor& x, std::vector<
 }
 template Tensor resnet_forward<float>(Ctx&, const ResNet&, const Tensor&, std::vector<Tensor>*);
 template TensorH resnet_forward<bf16>(Ctx&, const ResNet&, const Tensor&, std::vector<TensorH>*);
+template TensorF16 resnet_forward<f16>(Ctx&, const ResNet&, const Tensor&, std::vector<TensorF16>*);
 
 }  // namespace fe
 
@@ -579,28 +608,38 @@ void linear_forward_f32(Ctx& c, const ConvW& w, const float* x, int ldx, int M, 
   linear_forward(c, w, x, ldx, M, y, ldy, act);
 }
 
-void linear_forward(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16* y, int ldy, int act, const bf16* res, int ldr) {
-  FE_CHECK(w.wh, "linear(bf16): layer has no bf16 weights");
+template <class E>
+static void linear_forward_half(Ctx& c, const ConvW& w, const E* x, int ldx, int M, E* y, int ldy, int act, const E* res, int ldr) {
+  FE_CHECK(w.wh && w.hprec == PrecOf<E>::value, "linear(2-byte): layer has no weights of the activations' type");
   if (M <= 32 && !res && act != ACT_PRELU && ldx % 4 == 0 && ((uintptr_t)x & 7) == 0) {
-    launch_gemm_skinny(x, ldx, (const bf16*)w.wh, w.KpH, w.scale, w.shift, y, ldy, M, w.Cout, w.CinPadH, act, c.stream);
+    launch_gemm_skinny(x, ldx, (const E*)w.wh, w.KpH, w.scale, w.shift, y, ldy, M, w.Cout, w.CinPadH, act, c.stream);
     c.flops_accum += 2.0 * M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : w.Cout);
     return;
   }
-  TensorH xt = mat_view(x, M, w.CinPadH, ldx), yt = mat_view(y, M, w.Cout, ldy);
-  ConvOptsT<bf16> o; o.act = act;
-  TensorH rt;
+  TensorT<E> xt = mat_view(x, M, w.CinPadH, ldx), yt = mat_view(y, M, w.Cout, ldy);
+  ConvOptsT<E> o; o.act = act;
+  TensorT<E> rt;
   if (res) { rt = mat_view(res, M, w.Cout, ldr); o.res = &rt; }
   conv_forward(c, w, xt, yt, o);
 }
-// bf16 activations, fp32 results: the weight matrix is streamed once per block of 32 rows (heads only: M is a batch size)
-void linear_forward_f32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float* y, int ldy, int act) {
-  FE_CHECK(w.wh && act != ACT_PRELU && ldx % 4 == 0 && ((uintptr_t)x & 7) == 0, "linear_f32(bf16): unsupported layer");
+void linear_forward(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16* y, int ldy, int act, const bf16* res, int ldr) {
+  linear_forward_half<bf16>(c, w, x, ldx, M, y, ldy, act, res, ldr);
+}
+void linear_forward(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, f16* y, int ldy, int act, const f16* res, int ldr) {
+  linear_forward_half<f16>(c, w, x, ldx, M, y, ldy, act, res, ldr);
+}
+// 2-byte activations, fp32 results: the weight matrix is streamed once per block of 32 rows (heads only: M is a batch size)
+template <class E>
+static void linear_forward_f32_half(Ctx& c, const ConvW& w, const E* x, int ldx, int M, float* y, int ldy, int act) {
+  FE_CHECK(w.wh && w.hprec == PrecOf<E>::value && act != ACT_PRELU && ldx % 4 == 0 && ((uintptr_t)x & 7) == 0, "linear_f32(2-byte): unsupported layer");
   for (int m0 = 0; m0 < M; m0 += 32) {
     const int mb = std::min(32, M - m0);
-    launch_gemm_skinny(x + (size_t)m0 * ldx, ldx, (const bf16*)w.wh, w.KpH, w.scale, w.shift, y + (size_t)m0 * ldy, ldy, mb, w.Cout, w.CinPadH, act, c.stream);
+    launch_gemm_skinny(x + (size_t)m0 * ldx, ldx, (const E*)w.wh, w.KpH, w.scale, w.shift, y + (size_t)m0 * ldy, ldy, mb, w.Cout, w.CinPadH, act, c.stream);
   }
   c.flops_accum += 2.0 * M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : w.Cout);
 }
+void linear_forward_f32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float* y, int ldy, int act) { linear_forward_f32_half<bf16>(c, w, x, ldx, M, y, ldy, act); }
+void linear_forward_f32(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, float* y, int ldy, int act) { linear_forward_f32_half<f16>(c, w, x, ldx, M, y, ldy, act); }
 
 MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& prefix, int heads) {
   MHAW m;
@@ -621,10 +660,10 @@ MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& pref
   std::vector<float> bv(Bv.data.begin() + 2 * d, Bv.data.begin() + 3 * d);
   m.wv = dw.upload(wv);
   m.bv = dw.upload(bv);
-  if (dw.prec == PREC_BF16) {
+  if (dw.prec != PREC_F32) {
     std::vector<uint16_t> wvh(wv.size());
-    for (size_t i = 0; i < wv.size(); ++i) wvh[i] = f32_to_bf16_bits(wv[i]);
-    m.wv_h = (bf16*)dw.upload_raw(wvh.data(), wvh.size() * sizeof(uint16_t));
+    for (size_t i = 0; i < wv.size(); ++i) wvh[i] = f32_to_half_bits(wv[i], dw.prec);
+    m.wv_h = dw.upload_raw(wvh.data(), wvh.size() * sizeof(uint16_t));
   }
   m.out = build_linear(dw, ws, prefix + ".out_proj", true);
   return m;
@@ -632,6 +671,7 @@ MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& pref
 
 static void launch_gemm(const ConvParams& p, hipStream_t s) { launch_conv(p, s); }
 static void launch_gemm(const ConvParamsH& p, hipStream_t s) { launch_conv_bf16(p, s); }
+static void launch_gemm(const ConvParamsT<f16>& p, hipStream_t s) { launch_conv_bf16(p, s); }
 
 template <class T>
 static void raw_gemm(Ctx& c, ConvParamsT<T>& p, double flops) {
@@ -642,6 +682,9 @@ static void raw_gemm(Ctx& c, ConvParamsT<T>& p, double flops) {
   p.Kp = (p.K + kalign - 1) / kalign * kalign;
   p.Cin = p.K;
   FE_CHECK(p.xs1 % valign == 0 && p.xs2 % valign == 0 && p.ws1 % valign == 0 && p.ws2 % valign == 0, "raw_gemm: batch strides must keep 16-B alignment");
+  // K is rounded up to whole K-steps (Kp); the A side zero-fills its chunks past K, but a B operand that is a live activation
+  // matrix (ldw != Kp) would be read past K into neighbouring rows - 0 x NaN from stale arena bytes is NaN
+  FE_CHECK(p.ldw == 0 || p.ldw == p.Kp || p.K % kalign == 0, "raw_gemm: K = %d must be a multiple of %d when the B operand is an activation matrix", p.K, kalign);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c.profile) {
     FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
@@ -655,7 +698,7 @@ static void raw_gemm(Ctx& c, ConvParamsT<T>& p, double flops) {
     FE_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     char nm[128];
-    snprintf(nm, sizeof nm, "%sbgemm x%d M=%d K=%d N=%d", sizeof(T) == 2 ? "bf16 " : "", p.batch > 1 ? p.batch : 1, p.M, p.K, p.Cout);
+    snprintf(nm, sizeof nm, "%sbgemm x%d M=%d K=%d N=%d", PrecOf<T>::value == PREC_F16 ? "f16 " : (PrecOf<T>::value == PREC_BF16 ? "bf16 " : ""), p.batch > 1 ? p.batch : 1, p.M, p.K, p.Cout);
     c.timings.push_back({nm, flops, 0.0, ms});
   }
   c.flops_accum += flops;
@@ -663,8 +706,12 @@ static void raw_gemm(Ctx& c, ConvParamsT<T>& p, double flops) {
 
 static const float* mha_wv(const MHAW& m, const float*) { return m.wv; }
 static const bf16* mha_wv(const MHAW& m, const bf16*) {
-  FE_CHECK(m.wv_h, "mha(bf16): model was not committed under bf16 precision");
-  return m.wv_h;
+  FE_CHECK(m.wv_h && m.q.hprec == PREC_BF16, "mha(bf16): model was not committed under bf16 precision");
+  return (const bf16*)m.wv_h;
+}
+static const f16* mha_wv(const MHAW& m, const f16*) {
+  FE_CHECK(m.wv_h && m.q.hprec == PREC_F16, "mha(f16): model was not committed under f16 precision");
+  return (const f16*)m.wv_h;
 }
 
 template <class T>
@@ -726,5 +773,6 @@ void mha_forward(Ctx& c, const MHAW& m, const T* q_in, int ldq, const T* kv_in, 
 }
 template void mha_forward<float>(Ctx&, const MHAW&, const float*, int, const float*, int, int, int, int, const float*, int, float*, int, bool);
 template void mha_forward<bf16>(Ctx&, const MHAW&, const bf16*, int, const bf16*, int, int, int, int, const bf16*, int, bf16*, int, bool);
+template void mha_forward<f16>(Ctx&, const MHAW&, const f16*, int, const f16*, int, int, int, int, const f16*, int, f16*, int, bool);
 
 }  // namespace fe

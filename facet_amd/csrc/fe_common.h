@@ -70,6 +70,43 @@ __device__ __forceinline__ float fe_apply_act_fast(float v, int act) {   // bf16
 // bf16 storage type of the reduced-precision path (BASELINE configs[3]). hipcc lowers float <-> __bf16 casts to
 // v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN) / a 16-bit shift.
 typedef __bf16 bf16;
+// fp16 storage type: the reference's own reduced precision (`self.model.half()`, processing/scorer.py:513-516). 11 significant bits
+// against bf16's 8, the same matrix-core rate on gfx950 (v_mfma_f32_32x32x16_f16); the range ends at 65504, so every fp32 -> fp16
+// store of the engine saturates instead of producing an infinity.
+typedef _Float16 f16;
+constexpr float FE_F16_MAX = 65504.f;
+__device__ __forceinline__ f16 fe_to_f16(float v) { return (f16)__builtin_fminf(__builtin_fmaxf(v, -FE_F16_MAX), FE_F16_MAX); }
+
+// The two 2-byte element types share every kernel of the reduced-precision path through these overloads (tag = a null pointer of
+// the element type): unpack a 32-bit pair to two floats, pack two floats to a pair (round to nearest even).
+typedef __bf16 fe_bf2 __attribute__((ext_vector_type(2)));
+typedef _Float16 fe_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fe_unpack2(const bf16*, unsigned u, float& lo, float& hi) {
+  lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xFFFF0000u);
+}
+__device__ __forceinline__ void fe_unpack2(const f16*, unsigned u, float& lo, float& hi) {
+  const fe_h2 v = __builtin_bit_cast(fe_h2, u);
+  lo = (float)v[0]; hi = (float)v[1];
+}
+__device__ __forceinline__ unsigned fe_pack2(const bf16*, float lo, float hi) {
+  fe_bf2 v; v[0] = (bf16)lo; v[1] = (bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned fe_pack2(const f16*, float lo, float hi) {
+  fe_h2 v; v[0] = fe_to_f16(lo); v[1] = fe_to_f16(hi);
+  return __builtin_bit_cast(unsigned, v);
+}
+// one 32x32x16 matrix instruction on 8-element fragments held as four dwords
+typedef float fe_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 fe_bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fe_h8 __attribute__((ext_vector_type(8)));
+typedef float fe_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ fe_f32x16 fe_mfma16(const bf16*, fe_v4f a, fe_v4f b, fe_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fe_bf8, a), __builtin_bit_cast(fe_bf8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ fe_f32x16 fe_mfma16(const f16*, fe_v4f a, fe_v4f b, fe_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(fe_h8, a), __builtin_bit_cast(fe_h8, b), c, 0, 0, 0);
+}
 
 // A view of an NHWC activation in HBM (T = float, or bf16 on the reduced-precision path). `ld` is the channel stride of one
 // pixel (>= c) so a view can be a channel slice of a wider (concat) buffer.
@@ -89,18 +126,30 @@ struct TensorT {
 };
 using Tensor = TensorT<float>;
 using TensorH = TensorT<bf16>;
+using TensorF16 = TensorT<f16>;
 
 // element access shared by the fp32 and bf16 instantiations: arithmetic is always fp32, only loads / stores differ
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16* p) { return (float)*p; }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16* p, float v) { *p = (bf16)v; }
+__device__ __forceinline__ float ldf(const f16* p) { return (float)*p; }
+__device__ __forceinline__ void stf(f16* p, float v) { *p = fe_to_f16(v); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 ld4(const bf16* p) {
   const uint2 u = *reinterpret_cast<const uint2*>(p);
   return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
 }
+__device__ __forceinline__ float4 ld4(const f16* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  float4 v;
+  fe_unpack2(p, u.x, v.x, v.y); fe_unpack2(p, u.y, v.z, v.w);
+  return v;
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(f16* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(fe_pack2(p, v.x, v.y), fe_pack2(p, v.z, v.w));
+}
 __device__ __forceinline__ void st4(bf16* p, float4 v) {
   typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
   bf4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
@@ -197,10 +246,12 @@ struct ConvW {
   float* wino = nullptr;   // 3x3 convs with Cin >= 256 also carry Winograd F(2x2,3x3) weights U[16][Cout][Cin]
   float* wstem = nullptr;  // 7x7 or 3x3, Cin <= 3, Cout 32|64 stems also carry the [taps][Cout][4] layout of kernels_stem.hip
   int KpT = 0;
-  // bf16 path (models committed under FE_PRECISION_BF16): [Cout][KpH] bf16 in the K order of kernels_conv_bf16.hip
-  bf16* wh = nullptr;
+  // 2-byte path (models committed under FE_PRECISION_BF16 / FE_PRECISION_F16): [Cout][KpH] elements of type `hprec` in the K
+  // order of kernels_conv_bf16.hip
+  void* wh = nullptr;
+  int hprec = 0;           // element type of wh / wtap_h: 1 bf16, 2 f16 (Precision codes); the launch wrappers check it against T
   int KpH = 0, cb = 0, CinPadH = 0;   // CinPadH: input channels the bf16 kernel reads per pixel (Cin rounded up to 8)
-  bf16* wtap_h = nullptr;  // tap-decomposed form for Cout <= 2 spatial kernels, [KH*KW*Cout rounded to 8][KpTH]
+  void* wtap_h = nullptr;  // tap-decomposed form for Cout <= 2 spatial kernels, [KH*KW*Cout rounded to 8][KpTH]
   int KpTH = 0;
 };
 
@@ -230,6 +281,7 @@ bool launch_stem(const float* x, int ldx, int N, int H, int W, const float* wste
 void launch_conv_narrow(const ConvParams& p, hipStream_t s);            // Cout <= 4, no MFMA (kernels_misc.hip)
 void launch_conv_dma(const ConvParams& p, int tile, hipStream_t s);  // LDS-DMA fast path (kernels_conv_dma.hip)
 void launch_conv_bf16(const ConvParamsH& p, hipStream_t s);          // bf16 MFMA implicit GEMM (kernels_conv_bf16.hip)
+void launch_conv_bf16(const ConvParamsT<f16>& p, hipStream_t s);     // the same kernels on fp16 elements (kernels_conv_f16.hip)
 // A convolution over a batch of images whose input, output or residual tensor outgrows the 32-bit buffer addressing of the LDS-DMA
 // kernels (4 GiB: e.g. 64 fp32 images of 512 x 512 x 64) is issued as several launches over image groups that fit. Returns false when the
 // problem is not an image batch (GEMMs, batched launches) or a single image is already too large.
@@ -278,6 +330,8 @@ template <class T> void launch_bilinear(const TensorT<T>& x, const TensorT<T>& y
 template <class T> void launch_adaptive_avgpool(const TensorT<T>& x, const TensorT<T>& y, hipStream_t s);
 void launch_convert(const float* x, bf16* y, size_t n, hipStream_t s);
 void launch_convert(const bf16* x, float* y, size_t n, hipStream_t s);
+void launch_convert(const float* x, f16* y, size_t n, hipStream_t s);
+void launch_convert(const f16* x, float* y, size_t n, hipStream_t s);
 void launch_splitk_reduce(const float* part, int splits, int M, int N, const float* scale, const float* shift, const float* slope, int act,
                           const float* res, int ldr, int res_after_act, float* y, int ldy, hipStream_t s);
 // y = act(x) elementwise / y = x + r
@@ -289,8 +343,10 @@ void launch_tap_gather(const T* z, int ldz, int n, int h, int w, int kh, int kw,
 // fused attention, head_dim 64 (kernels_attn.hip): o = softmax(q k^T) v + bv per (batch, head)
 void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* vt, int lp, const float* bv, float* o,
                       int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s);
-// bf16 twin (kernels_attn_bf16.hip): bf16 Q / K / V^T / O, fp32 softmax and accumulation
+// 2-byte twins (kernels_attn_bf16.hip): bf16 or fp16 Q / K / V^T / O, fp32 softmax and accumulation
 void launch_attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* vt, int lp, const float* bv, bf16* o,
+                      int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s);
+void launch_attention(const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int lp, const float* bv, f16* o,
                       int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s);
 // M <= 32 rows: one wave per output column (kernels_misc.hip); TI / TW / TO = activation / weight / output element types
 template <class TI, class TW, class TO>
@@ -299,8 +355,8 @@ void launch_gemm_skinny(const TI* x, int ldx, const TW* w, int ldw, const float*
 void launch_sigmoid(const Tensor& x, const Tensor& y, hipStream_t s);
 void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s);
 // LayerNorm over last dim of a [rows][d] matrix (eps inside sqrt, biased variance); statistics in fp32
-template <class T>
-void launch_layernorm(const T* x, int ldx, T* y, int ldy, const float* g, const float* b,
+template <class T, class TO>   // TO = T, or a 2-byte TO behind fp32 rows (the fp32 residual stream of the reduced-precision path)
+void launch_layernorm(const T* x, int ldx, TO* y, int ldy, const float* g, const float* b,
                       int rows, int d, float eps, hipStream_t s);
 // rows softmax in place for [rows][d]
 void launch_softmax_rows(float* x, int ld, int rows, int d, hipStream_t s);

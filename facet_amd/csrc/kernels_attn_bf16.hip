@@ -17,35 +17,35 @@
 namespace fe {
 
 typedef float ah_f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 ah_bf8 __attribute__((ext_vector_type(8)));
-typedef __bf16 ah_bf4 __attribute__((ext_vector_type(4)));
+// E = bf16 | f16 (fe_common.h: fe_mfma16 / fe_pack2 overloads): one source for both 2-byte types
 
 constexpr int ATH_KS = 144;   // K tile row stride in BYTES: 128 + 16 -> conflict-free ds_read_b128 over rows distinct mod 16
 constexpr int ATH_VS = 72;    // V^T tile row stride in BYTES: 64 + 8 -> conflict-free ds_read_b64 over 32 rows
 
+template <class E>
 struct AttnParamsH {
-  const bf16* q; int ldq;      // [B*Lq][ldq], head h at column h*64
-  const bf16* k; int ldk;      // [B*Lk][ldk]
-  const bf16* vt; int lp;      // [B][d_model][lp]  (V transposed, zero padded to lp >= roundup32(Lk))
+  const E* q; int ldq;         // [B*Lq][ldq], head h at column h*64
+  const E* k; int ldk;         // [B*Lk][ldk]
+  const E* vt; int lp;         // [B][d_model][lp]  (V transposed, zero padded to lp >= roundup32(Lk))
   const float* bv;             // [d_model] V bias, added to the output (softmax rows sum to 1)
-  bf16* o; int ldo;            // [B*Lq][ldo]
+  E* o; int ldo;               // [B*Lq][ldo]
   int B, H, Lq, Lk, dmodel;
   int causal;
 };
 
-union AH8 { uint4 u; ah_bf8 b; };
-union AH4 { uint2 u; ah_bf4 b; };
+union AH8 { uint4 u; fe_v4f f; };
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_kernel(const AttnParamsH p) {
+template <class E, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_kernel(const AttnParamsH<E> p) {
+  const E* const tag = nullptr;
   __shared__ __attribute__((aligned(16))) char Ks[2][32 * ATH_KS];
   __shared__ __attribute__((aligned(16))) char Vs[2][64 * ATH_VS];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
-  const bf16* Qp = p.q + (size_t)b * p.Lq * p.ldq + head * 64;
-  const bf16* Kp = p.k + (size_t)b * p.Lk * p.ldk + head * 64;
-  const bf16* Vp = p.vt + ((size_t)b * p.dmodel + head * 64) * p.lp;
+  const E* Qp = p.q + (size_t)b * p.Lq * p.ldq + head * 64;
+  const E* Kp = p.k + (size_t)b * p.Lk * p.ldk + head * 64;
+  const E* Vp = p.vt + ((size_t)b * p.dmodel + head * 64) * p.lp;
 
   const int q = (blockIdx.x * NW + wave) * 32 + r;
   const bool qok = q < p.Lq;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_kernel(const AttnPar
     for (int s = 0; s < 4; ++s) {
       AH8 kf;
       kf.u = *reinterpret_cast<const uint4*>(kb + 32 * s);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.b, qf[s].b, st, 0, 0, 0);
+      st = fe_mfma16(tag, kf.f, qf[s].f, st);
     }
     // ---- online softmax over this lane's query -----------------------------------------------------------
     const int kbase = kt * 32 + 4 * h;
@@ -137,15 +137,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_kernel(const AttnPar
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       AH8 pf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf.b[j] = (bf16)st[8 * s + j];
+      pf.u = make_uint4(fe_pack2(tag, st[8 * s], st[8 * s + 1]), fe_pack2(tag, st[8 * s + 2], st[8 * s + 3]),
+                        fe_pack2(tag, st[8 * s + 4], st[8 * s + 5]), fe_pack2(tag, st[8 * s + 6], st[8 * s + 7]));
       AH8 v0, v1;   // V^T[d = r (+32)][keys 16s + 4h .. +4 | 16s + 8 + 4h .. +4]
       const uint2 a0 = *reinterpret_cast<const uint2*>(vb + 32 * s), a1 = *reinterpret_cast<const uint2*>(vb + 32 * s + 16);
       const uint2 c0 = *reinterpret_cast<const uint2*>(vb + 32 * ATH_VS + 32 * s), c1 = *reinterpret_cast<const uint2*>(vb + 32 * ATH_VS + 32 * s + 16);
       v0.u = make_uint4(a0.x, a0.y, a1.x, a1.y);
       v1.u = make_uint4(c0.x, c0.y, c1.x, c1.y);
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0.b, pf.b, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1.b, pf.b, o1, 0, 0, 0);
+      o0 = fe_mfma16(tag, v0.f, pf.f, o0);
+      o1 = fe_mfma16(tag, v1.f, pf.f, o1);
     }
     if (kt + 1 < nt) ATH_STORE_TILE(buf ^ 1)
     __syncthreads();
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_kernel(const AttnPar
   // ---- epilogue: O[q][head*64 + d] = O^T[d][q] / l + bv[d]; register e of tile dt is d = 32*dt + (e&3) + 8(e>>2) + 4h
   if (qok) {
     const float inv = 1.f / l;
-    bf16* op = p.o + ((size_t)b * p.Lq + q) * p.ldo + head * 64;
+    E* op = p.o + ((size_t)b * p.Lq + q) * p.ldo + head * 64;
     const float* bp = p.bv + head * 64;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -166,19 +166,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_kernel(const AttnPar
   }
 }
 
-void launch_attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* vt, int lp, const float* bv, bf16* o,
-                      int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s) {
+template <class E>
+static void launch_attention_half(const E* q, int ldq, const E* k, int ldk, const E* vt, int lp, const float* bv, E* o,
+                                  int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s) {
   FE_CHECK(dmodel == H * 64, "attention kernel is built for head_dim 64 (d_model %d, %d heads)", dmodel, H);
-  FE_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && lp % 4 == 0 && ldo % 4 == 0 && lp >= (Lk + 31) / 32 * 32, "attention(bf16): strides");
-  FE_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)bv) & 15) == 0 && (((uintptr_t)vt | (uintptr_t)o) & 7) == 0, "attention(bf16): alignment");
-  AttnParamsH p{q, ldq, k, ldk, vt, lp, bv, o, ldo, B, H, Lq, Lk, dmodel, causal};
+  FE_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && lp % 4 == 0 && ldo % 4 == 0 && lp >= (Lk + 31) / 32 * 32, "attention(2-byte): strides");
+  FE_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)bv) & 15) == 0 && (((uintptr_t)vt | (uintptr_t)o) & 7) == 0, "attention(2-byte): alignment");
+  AttnParamsH<E> p{q, ldq, k, ldk, vt, lp, bv, o, ldo, B, H, Lq, Lk, dmodel, causal};
   const int w4 = (Lq + 127) / 128 * 128, w2 = (Lq + 63) / 64 * 64;
   if (w4 * 100 <= w2 * 108) {
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, dim3((Lq + 127) / 128, B * H), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<E, 4>), dim3((Lq + 127) / 128, B * H), dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, dim3((Lq + 63) / 64, B * H), dim3(128), 0, s, p);
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<E, 2>), dim3((Lq + 63) / 64, B * H), dim3(128), 0, s, p);
   }
   FE_HIP(hipGetLastError());
+}
+void launch_attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16* vt, int lp, const float* bv, bf16* o,
+                      int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s) {
+  launch_attention_half(q, ldq, k, ldk, vt, lp, bv, o, ldo, B, H, Lq, Lk, dmodel, causal, s);
+}
+void launch_attention(const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int lp, const float* bv, f16* o,
+                      int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s) {
+  launch_attention_half(q, ldq, k, ldk, vt, lp, bv, o, ldo, B, H, Lq, Lk, dmodel, causal, s);
 }
 
 }  // namespace fe

@@ -1,36 +1,42 @@
-// bf16 implicit-GEMM convolution: tile policy, launcher and the narrow-tile instantiations (kernel: conv_bf16_kernel.h).
+// 2-byte (bf16 / fp16) implicit-GEMM convolution: tile policy, launcher and the narrow-tile instantiations (kernel: conv_bf16_kernel.h).
+// FE_E = element type of this translation unit: bf16 here, f16 through kernels_conv_f16.hip, which includes this file.
 #include "conv_bf16_kernel.h"
+#ifndef FE_E
+#define FE_E bf16
+#endif
 
 namespace fe {
 
+typedef ConvParamsT<FE_E> ConvParamsE;
+
 template <int UNITS>
-static void launch_bf16_tile(const ConvParamsH& p, int tile, bool one_tap, hipStream_t s) {
+static void launch_bf16_tile(const ConvParamsE& p, int tile, bool one_tap, hipStream_t s) {
   FE_CHECK(p.act != ACT_PRELU, "conv_bf16: PReLU epilogue is not instantiated (no bf16 model uses it)");
   if constexpr (UNITS == 1) {
     if (one_tap) {      // 1x1 kernels with Cin % 64 == 0: K offset as the scalar offset of the loads, no tap masks
       switch (tile) {
-        case 1: launch_bf16_variant<2, 2, 2, 2, 1, 0, true>(p, s); return;   // 128x128
-        case 8: launch_bf16_variant<2, 2, 4, 2, 1, 0, true>(p, s); return;   // 256x128, waves of 128x64
-        case 9: launch_bf16_variant<2, 4, 4, 2, 1, 0, true>(p, s); return;   // 256x256, eight waves of 128x64, one workgroup per CU
-        case 7: launch_bf16_variant<2, 2, 2, 1, 1, 0, true>(p, s); return;   // 128x64
-        case 4: launch_bf16_variant<2, 2, 1, 1, 1, 0, true>(p, s); return;   // 64x64
+        case 1: launch_bf16_variant<FE_E, 2, 2, 2, 2, 1, 0, true>(p, s); return;   // 128x128
+        case 8: launch_bf16_variant<FE_E, 2, 2, 4, 2, 1, 0, true>(p, s); return;   // 256x128, waves of 128x64
+        case 9: launch_bf16_variant<FE_E, 2, 4, 4, 2, 1, 0, true>(p, s); return;   // 256x256, eight waves of 128x64, one workgroup per CU
+        case 7: launch_bf16_variant<FE_E, 2, 2, 2, 1, 1, 0, true>(p, s); return;   // 128x64
+        case 4: launch_bf16_variant<FE_E, 2, 2, 1, 1, 1, 0, true>(p, s); return;   // 64x64
         default: break;
       }
     }
   }
   switch (tile) {
-    case 1: launch_bf16_variant<2, 2, 2, 2, UNITS>(p, s); break;   // 128x128
-    case 8: launch_bf16_variant<2, 2, 4, 2, UNITS>(p, s); break;   // 256x128
-    case 7: launch_bf16_variant<2, 2, 2, 1, UNITS>(p, s); break;   // 128x64
-    case 4: launch_bf16_variant<2, 2, 1, 1, UNITS>(p, s); break;   // 64x64
-    case 3: launch_bf16_variant<4, 1, 2, 1, UNITS>(p, s); break;   // 256x32
-    case 5: launch_bf16_variant<4, 1, 1, 1, UNITS>(p, s); break;   // 128x32
+    case 1: launch_bf16_variant<FE_E, 2, 2, 2, 2, UNITS>(p, s); break;   // 128x128
+    case 8: launch_bf16_variant<FE_E, 2, 2, 4, 2, UNITS>(p, s); break;   // 256x128
+    case 7: launch_bf16_variant<FE_E, 2, 2, 2, 1, UNITS>(p, s); break;   // 128x64
+    case 4: launch_bf16_variant<FE_E, 2, 2, 1, 1, UNITS>(p, s); break;   // 64x64
+    case 3: launch_bf16_variant<FE_E, 4, 1, 2, 1, UNITS>(p, s); break;   // 256x32
+    case 5: launch_bf16_variant<FE_E, 4, 1, 1, 1, UNITS>(p, s); break;   // 128x32
     default: FE_CHECK(false, "conv_bf16: unknown tile %d", tile);
   }
 }
 
-void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
-  ConvParamsH p = p0;
+void launch_conv_bf16(const ConvParamsE& p0, hipStream_t s) {
+  ConvParamsE p = p0;
   FE_CHECK(p.x && p.w && p.y && p.ldy >= p.Cout && p.ldx >= p.Cin, "conv_bf16: null operand or row stride below the channel count");
   if (p.ldw == 0) p.ldw = p.Kp;
   if (p.batch < 1) p.batch = 1;
@@ -50,7 +56,7 @@ void launch_conv_bf16(const ConvParamsH& p0, hipStream_t s) {
   const unsigned long long ws = ((unsigned long long)p.Cout - 1) * (unsigned long long)p.ldw * 2 + (unsigned long long)p.Kp * 2;
   {      // tensors past 4 GiB (input, or the output / residual the wide tiles address through buffers): image groups that fit
     const unsigned long long ysp = (unsigned long long)p.M * (unsigned long long)(p.ldy > p.ldr ? p.ldy : p.ldr) * 2;
-    if ((xs >= 0xFFFFFF00ull || ysp >= 0xFFFFFF00ull) && conv_split_by_images(p, [&](const ConvParamsH& sub) { launch_conv_bf16(sub, s); })) return;
+    if ((xs >= 0xFFFFFF00ull || ysp >= 0xFFFFFF00ull) && conv_split_by_images(p, [&](const ConvParamsE& sub) { launch_conv_bf16(sub, s); })) return;
   }
   FE_CHECK(xs < 0xFFFFFF00ull && ws < 0xFFFFFF00ull, "conv_bf16: operand spans exceed 32-bit buffer addressing");
   p.x_span = (unsigned)xs; p.w_span = (unsigned)ws;

@@ -1,9 +1,13 @@
-// bf16 implicit-GEMM convolution: wide-tile instantiations (a share of them per translation unit: see conv_bf16_kernel.h).
+// 2-byte implicit-GEMM convolution: wide-tile instantiations (a share of them per translation unit: see conv_bf16_kernel.h).
+// FE_E = element type of this translation unit: bf16 here, f16 through kernels_conv_f16_wide2.hip, which includes this file.
 #include "conv_bf16_kernel.h"
+#ifndef FE_E
+#define FE_E bf16
+#endif
 
 namespace fe {
 
-template void launch_bf16_variant<2, 2, 2, 2, 1, 0, false>(const ConvParamsH&, hipStream_t);
-template void launch_bf16_variant<2, 2, 4, 2, 1, 0, false>(const ConvParamsH&, hipStream_t);
+template void launch_bf16_variant<FE_E, 2, 2, 2, 2, 1, 0, false>(const ConvParamsT<FE_E>&, hipStream_t);
+template void launch_bf16_variant<FE_E, 2, 2, 4, 2, 1, 0, false>(const ConvParamsT<FE_E>&, hipStream_t);
 
 }  // namespace fe

@@ -448,8 +448,8 @@ void launch_gemm_skinny(const TI* x, int ldx, const TW* w, int ldw, const float*
 }
 
 // ---- LayerNorm: one wave per row, two-pass (mean, then centred variance) in registers ------------------
-template <class T>
-__global__ void layernorm_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+template <class T, class TO>
+__global__ void layernorm_kernel(const T* __restrict__ x, int ldx, TO* __restrict__ y, int ldy,
                                  const float* __restrict__ g, const float* __restrict__ b, int rows, int d, float eps) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -466,15 +466,15 @@ __global__ void layernorm_kernel(const T* __restrict__ x, int ldx, T* __restrict
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
     const float rstd = 1.0f / sqrtf(var / (float)d + eps);
-    T* yr = y + (size_t)row * ldy;
+    TO* yr = y + (size_t)row * ldy;
     for (int i = lane; i < d; i += 64) stf(yr + i, (ldf(xr + i) - mean) * rstd * g[i] + b[i]);
   }
 }
 // Register-resident form for d = 256 * NV (the ViT / CFANet widths 256, 768, 1024): one wave per row, every lane holds 4 * NV
 // consecutive-by-256 elements (8- or 16-byte loads: whole 512-B / 1-KiB segments per wave instruction), ONE read and one write of
 // the row; mean, then centred variance, both in fp32 registers.
-template <class T, int NV>
-__global__ void layernorm_reg_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+template <class T, class TO, int NV>
+__global__ void layernorm_reg_kernel(const T* __restrict__ x, int ldx, TO* __restrict__ y, int ldy,
                                      const float* __restrict__ g, const float* __restrict__ b, int rows, float eps) {
   constexpr int d = 256 * NV;
   const int lane = threadIdx.x & 63;
@@ -504,23 +504,24 @@ __global__ void layernorm_reg_kernel(const T* __restrict__ x, int ldx, T* __rest
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
     const float rstd = 1.0f / sqrtf(var / (float)d + eps);
-    T* yr = y + (size_t)row * ldy;
+    TO* yr = y + (size_t)row * ldy;
 #pragma unroll
     for (int k = 0; k < NV; ++k)
       st4(yr + 256 * k + 4 * lane, make_float4(v[k].x * rstd * gv[k].x + bv[k].x, v[k].y * rstd * gv[k].y + bv[k].y,
                                                v[k].z * rstd * gv[k].z + bv[k].z, v[k].w * rstd * gv[k].w + bv[k].w));
   }
 }
-template <class T>
-void launch_layernorm(const T* x, int ldx, T* y, int ldy, const float* g, const float* b, int rows, int d,
+template <class T, class TO>
+void launch_layernorm(const T* x, int ldx, TO* y, int ldy, const float* g, const float* b, int rows, int d,
                       float eps, hipStream_t s) {
   const int blocks = grid_for((size_t)rows * 64);
-  const bool vec = d % 256 == 0 && d <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && vec4_ok(x, y) && ((((uintptr_t)g | (uintptr_t)b) & 15) == 0);
-  if (vec && d == 256) hipLaunchKernelGGL((layernorm_reg_kernel<T, 1>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
-  else if (vec && d == 512) hipLaunchKernelGGL((layernorm_reg_kernel<T, 2>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
-  else if (vec && d == 768) hipLaunchKernelGGL((layernorm_reg_kernel<T, 3>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
-  else if (vec && d == 1024) hipLaunchKernelGGL((layernorm_reg_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
-  else hipLaunchKernelGGL(layernorm_kernel<T>, dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, d, eps);
+  const bool vec = d % 256 == 0 && d <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x & (4 * sizeof(T) - 1)) == 0 && ((uintptr_t)y & (4 * sizeof(TO) - 1)) == 0 &&
+                   ((((uintptr_t)g | (uintptr_t)b) & 15) == 0);
+  if (vec && d == 256) hipLaunchKernelGGL((layernorm_reg_kernel<T, TO, 1>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  else if (vec && d == 512) hipLaunchKernelGGL((layernorm_reg_kernel<T, TO, 2>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  else if (vec && d == 768) hipLaunchKernelGGL((layernorm_reg_kernel<T, TO, 3>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  else if (vec && d == 1024) hipLaunchKernelGGL((layernorm_reg_kernel<T, TO, 4>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<T, TO>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, d, eps);
   FE_HIP(hipGetLastError());
 }
 
@@ -675,6 +676,14 @@ void launch_convert(const bf16* x, float* y, size_t n, hipStream_t s) {
   hipLaunchKernelGGL((convert_kernel<bf16, float>), dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
   FE_HIP(hipGetLastError());
 }
+void launch_convert(const float* x, f16* y, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL((convert_kernel<float, f16>), dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+  FE_HIP(hipGetLastError());
+}
+void launch_convert(const f16* x, float* y, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL((convert_kernel<f16, float>), dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+  FE_HIP(hipGetLastError());
+}
 
 #define FE_INST_T(T)                                                                                                              \
   template void launch_nchw_to_nhwc<T>(const float*, T*, int, int, int, int, int, hipStream_t);                                  \
@@ -683,14 +692,20 @@ void launch_convert(const bf16* x, float* y, size_t n, hipStream_t s) {
   template void launch_bilinear<T>(const TensorT<T>&, const TensorT<T>&, hipStream_t);                                           \
   template void launch_adaptive_avgpool<T>(const TensorT<T>&, const TensorT<T>&, hipStream_t);                                   \
   template void launch_tap_gather<T>(const T*, int, int, int, int, int, int, int, int, int, int, int, const float*, const float*, int, T*, int, int, int, hipStream_t); \
-  template void launch_layernorm<T>(const T*, int, T*, int, const float*, const float*, int, int, float, hipStream_t);           \
+  template void launch_layernorm<T, T>(const T*, int, T*, int, const float*, const float*, int, int, float, hipStream_t);        \
   template void launch_add_rows_bcast<T>(T*, int, const float*, int, int, int, hipStream_t);
 FE_INST_T(float)
 FE_INST_T(bf16)
+FE_INST_T(f16)
 #undef FE_INST_T
+// fp32 residual stream in front of a 2-byte GEMM operand (precision option FE_PRECISION_RES32): LayerNorm reads fp32, writes 2 bytes
+template void launch_layernorm<float, bf16>(const float*, int, bf16*, int, const float*, const float*, int, int, float, hipStream_t);
+template void launch_layernorm<float, f16>(const float*, int, f16*, int, const float*, const float*, int, int, float, hipStream_t);
 template void launch_gemm_skinny<float, float, float>(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 template void launch_gemm_skinny<bf16, bf16, bf16>(const bf16*, int, const bf16*, int, const float*, const float*, bf16*, int, int, int, int, int, hipStream_t);
 template void launch_gemm_skinny<bf16, bf16, float>(const bf16*, int, const bf16*, int, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+template void launch_gemm_skinny<f16, f16, f16>(const f16*, int, const f16*, int, const float*, const float*, f16*, int, int, int, int, int, hipStream_t);
+template void launch_gemm_skinny<f16, f16, float>(const f16*, int, const f16*, int, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 
 // RGB <-> BGR of a packed uint8 image batch (the reference keeps a PIL RGB and a cv2 BGR copy of every image,
 // processing/batch_processor.py:200-215; here the second one is made on the device from the resident first one).

@@ -127,9 +127,9 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(StemParamsT<TO> p) {
 // 8th has zero weights) so taps pair up as (ky, 2t), (ky, 2t+1): one pair = two neighbouring pixels x 4 channels = 16 contiguous,
 // 16-byte aligned bytes of the patch = one ds_read_b128 = a lane's 8 k-values of one v_mfma_f32_32x32x16_bf16 (lanes 0-31 feed
 // pair 2u, lanes 32-63 pair 2u+1). 28 pairs = 14 MFMAs of 32 cycles per 32x32 tile instead of 75 fp32 MFMAs of 64.
-typedef __bf16 stem_bf8 __attribute__((ext_vector_type(8)));
-template <int TN>
-__global__ __launch_bounds__(256, 2) void stem7_bf16_kernel(StemParamsT<bf16> p) {
+// TO = bf16 | f16: the element type of the model the stem feeds (same kernel, the other matrix instruction).
+template <int TN, class TO>
+__global__ __launch_bounds__(256, 2) void stem7_bf16_kernel(StemParamsT<TO> p) {
   constexpr int K = 7, S = 2, P = 3;
   constexpr int PH = (STEM_TH - 1) * S + K;            // 21 patch rows
   constexpr int PW = (STEM_TW - 1) * S + K + 1;        // 69 patch columns + 1: rows stay 16-byte aligned at 8 bytes per pixel
@@ -142,9 +142,7 @@ __global__ __launch_bounds__(256, 2) void stem7_bf16_kernel(StemParamsT<bf16> p)
   const int r = lane & 31, h = lane >> 5;
   const int ox0 = blockIdx.x * STEM_TW, oy0 = blockIdx.y * STEM_TH, img = blockIdx.z;
   auto pack4 = [](const float4 v) -> uint2 {
-    union { bf16 b[4]; uint2 u; } o;
-    o.b[0] = (bf16)v.x; o.b[1] = (bf16)v.y; o.b[2] = (bf16)v.z; o.b[3] = (bf16)v.w;
-    return o.u;
+    return make_uint2(fe_pack2((const TO*)nullptr, v.x, v.y), fe_pack2((const TO*)nullptr, v.z, v.w));
   };
   const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
   for (int i = t; i < PH * PW; i += 256) {
@@ -179,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void stem7_bf16_kernel(StemParamsT<bf16> p)
   for (int u = 0; u < PAIRS / 2; ++u) {
     const int pair = 2 * u + h;
     const int ky = pair >> 2, kx = (pair & 3) * 2;
-    union { uint4 u4; stem_bf8 b; } a[TN], b[2];
+    union { uint4 u4; fe_v4f f; } a[TN], b[2];
 #pragma unroll
     for (int j = 0; j < TN; ++j) a[j].u4 = wl[pair * CO + j * 32 + r];
 #pragma unroll
@@ -187,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void stem7_bf16_kernel(StemParamsT<bf16> p)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j].b, b[i].b, acc[j][i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[j][i] = fe_mfma16((const TO*)nullptr, a[j].f, b[i].f, acc[j][i]);
   }
 
   // ---- epilogue: as stem_kernel (lane (r, h) holds couts (e&3) + 8(e>>2) + 4h of pixel r) --------------------------------
@@ -218,16 +216,16 @@ __global__ __launch_bounds__(256, 2) void stem7_bf16_kernel(StemParamsT<bf16> p)
   }
 }
 
-template <int TN>
-static void launch_stem7_bf16(const StemParamsT<bf16>& p, hipStream_t s) {
+template <int TN, class TO>
+static void launch_stem7_bf16(const StemParamsT<TO>& p, hipStream_t s) {
   constexpr int PH = (STEM_TH - 1) * 2 + 7, PW = (STEM_TW - 1) * 2 + 7 + 1;
   constexpr size_t main_lds = (size_t)((PH * PW + 1) / 2) * 16 + (size_t)28 * TN * 32 * 16;
   constexpr size_t epi_lds = (size_t)4 * 64 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   static std::atomic<uint64_t> lds_set{0};
-  ensure_dynamic_lds((const void*)stem7_bf16_kernel<TN>, lds, lds_set);
+  ensure_dynamic_lds((const void*)stem7_bf16_kernel<TN, TO>, lds, lds_set);
   const dim3 grid((p.Wo + STEM_TW - 1) / STEM_TW, (p.Ho + STEM_TH - 1) / STEM_TH, p.N);
-  hipLaunchKernelGGL((stem7_bf16_kernel<TN>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((stem7_bf16_kernel<TN, TO>), grid, dim3(256), lds, s, p);
   FE_HIP(hipGetLastError());
 }
 
@@ -258,7 +256,7 @@ bool launch_stem(const float* x, int ldx, int N, int H, int W, const float* wste
   if constexpr (sizeof(TO) == 2) {      // a stem that feeds the bf16 path: 7x7 / 2 on the bf16 matrix cores
     static const bool f32_stem = getenv("FE_BF16_STEM_F32") != nullptr;      // A/B hook: keep the fp32 products
     if (key == 72 && act != 2 && !f32_stem) {
-      if (Cout == 64) launch_stem7_bf16<2>(p, s); else launch_stem7_bf16<1>(p, s);
+      if (Cout == 64) launch_stem7_bf16<2, TO>(p, s); else launch_stem7_bf16<1, TO>(p, s);
       return true;
     }
   }
@@ -279,5 +277,7 @@ template bool launch_stem<float>(const float*, int, int, int, int, const float*,
                                  hipStream_t);
 template bool launch_stem<bf16>(const float*, int, int, int, int, const float*, const float*, const float*, const float*, int, int, int, int, bf16*, int, int, int,
                                 hipStream_t);
+template bool launch_stem<f16>(const float*, int, int, int, int, const float*, const float*, const float*, const float*, int, int, int, int, f16*, int, int, int,
+                               hipStream_t);
 
 }  // namespace fe

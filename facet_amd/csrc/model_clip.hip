@@ -207,6 +207,7 @@ void clip_forward(Ctx& c, const ClipModel& m, const Tensor& x, float* feat) {
 }
 template void clip_forward<float>(Ctx&, const ClipModel&, const Tensor&, float*);
 template void clip_forward<bf16>(Ctx&, const ClipModel&, const Tensor&, float*);
+template void clip_forward<f16>(Ctx&, const ClipModel&, const Tensor&, float*);
 
 // raw[b] = Linear(256,1)(relu(Linear(768,256)(feat[b])))   (reference scorer.py:579-583; (x+1)*5 clamp stays on host)
 void aesthetic_forward(Ctx& c, const AestheticModel& m, const float* feat, int B, float* raw) {

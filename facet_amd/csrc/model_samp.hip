@@ -148,6 +148,7 @@ void u2netp_forward(Ctx& c, const U2NetPModel& m, const Tensor& x, const TensorT
 }
 template void u2netp_forward<float>(Ctx&, const U2NetPModel&, const Tensor&, const Tensor&);
 template void u2netp_forward<bf16>(Ctx&, const U2NetPModel&, const Tensor&, const TensorH&);
+template void u2netp_forward<f16>(Ctx&, const U2NetPModel&, const Tensor&, const TensorF16&);
 
 // ---------------------------------------------------------------------------------------------------
 // SAMP-Net
@@ -329,5 +330,6 @@ void sampnet_forward(Ctx& c, const SampModel& m, const Tensor& x, const TensorT<
 }
 template void sampnet_forward<float>(Ctx&, const SampModel&, const Tensor&, const Tensor&, float*, float*, float*);
 template void sampnet_forward<bf16>(Ctx&, const SampModel&, const Tensor&, const TensorH&, float*, float*, float*);
+template void sampnet_forward<f16>(Ctx&, const SampModel&, const Tensor&, const TensorF16&, float*, float*, float*);
 
 }  // namespace fe

@@ -230,5 +230,6 @@ void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<TensorT<T>>& fe
 }
 template void topiq_head_forward<float>(Ctx&, TopiqModel&, const std::vector<Tensor>&, float*);
 template void topiq_head_forward<bf16>(Ctx&, TopiqModel&, const std::vector<TensorH>&, float*);
+template void topiq_head_forward<f16>(Ctx&, TopiqModel&, const std::vector<TensorF16>&, float*);
 
 }  // namespace fe

@@ -59,13 +59,19 @@ int fe_sync(fe_ctx* ctx);
 int fe_set_microbatch(fe_ctx* ctx, int n);
 
 /* Precision of the models committed AFTER this call (each model keeps the one it was committed under; FE_MODEL_AESTHETIC, the CLIP
- * text tower and the ONNX face graphs always run in fp32). FE_PRECISION_BF16 = BASELINE.json configs[3]: bf16 activations and weights
- * in HBM on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16) with fp32 accumulation, fp32 LayerNorm / softmax statistics, fp32 score
- * heads and fp32 outputs; the 3-channel first layers stay on the fp32 kernels. The reference does the same on a GPU for CLIP
- * (`model.half()`, processing/scorer.py:513-516). Default FE_PRECISION_F32 (the reference's CPU path). */
-enum fe_precision { FE_PRECISION_F32 = 0, FE_PRECISION_BF16 = 1 };
+ * text tower and the ONNX face graphs always run in fp32).
+ *   FE_PRECISION_F32   default: the arithmetic of the reference's CPU path.
+ *   FE_PRECISION_F16   what the reference itself runs on a GPU for CLIP (`self.model.half()`, processing/scorer.py:513-516): fp16
+ *                      activations and weights in HBM on the matrix cores (v_mfma_f32_32x32x16_f16), fp32 accumulation, fp32
+ *                      LayerNorm / softmax statistics, fp32 score heads and outputs; stores saturate at +-65504.
+ *   FE_PRECISION_BF16  BASELINE.json configs[3]: the same with bf16 storage (v_mfma_f32_32x32x16_bf16; 8 significant bits against
+ *                      fp16's 11, fp32's exponent range).
+ *   | FE_PRECISION_RES32  (or-ed onto a 2-byte precision) the residual / skip streams of the network (the ViT token stream, the ResNet
+ *                      skip path) and the inputs of every LayerNorm stay fp32; only the GEMM operands are 2 bytes.
+ * CLIP's 14x14 patch embedding and the non-7x7 three-channel first layers stay on the fp32 kernels in every precision. */
+enum fe_precision { FE_PRECISION_F32 = 0, FE_PRECISION_BF16 = 1, FE_PRECISION_F16 = 2, FE_PRECISION_RES32 = 16 };
 int fe_set_precision(fe_ctx* ctx, int precision);
-int fe_model_precision(fe_ctx* ctx, int model); /* fe_precision of a loaded model, -1 when it is not loaded */
+int fe_model_precision(fe_ctx* ctx, int model); /* enum fe_precision value of a loaded model, with its RES32 bit; -1 when it is not loaded */
 
 /* ---- device buffers (so callers can keep batches resident in HBM without torch) ------------- */
 int fe_dev_alloc(fe_ctx* ctx, size_t bytes, void** d_out);

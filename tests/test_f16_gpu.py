@@ -1,0 +1,77 @@
+"""GPU: the fp16 element type of the 2-byte kernel family - the reference's own reduced precision (`self.model.half()` on CLIP,
+processing/scorer.py:513-516) - against torch's fp32 arithmetic on the same fp16-rounded inputs, and whole models against the
+fp32 oracle.
+
+Tolerances:
+  * one contraction (fe_op_conv2d under f16 precision) against torch's fp32 convolution of the SAME fp16-rounded inputs: products are
+    exact, accumulation is fp32, the result is rounded once to fp16 (2^-12 relative): |diff| <= 2^-11 * |ref| + 2e-4 * max|ref|.
+  * stores saturate at +-65504 (no infinities leave a layer).
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_bf16_gpu import CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engf16():
+    from facet_amd import Engine
+    e = Engine(0, arena_bytes=16 << 30, precision="f16")
+    yield e
+    e.close()
+
+
+def _r16(a):
+    return torch.from_numpy(np.asarray(a, np.float32)).half().float()
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_f16_contraction_matches_fp32_on_rounded_inputs(engf16, case):
+    n, cin, h, w, cout, k, stride, pad, dil, act, with_res = case
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    x = _r16(rng.normal(0, 1, (n, cin, h, w)))
+    wt = _r16(rng.normal(0, 1.0 / np.sqrt(cin * k * k), (cout, cin, k, k)))
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.2, cout).astype(np.float32)
+    ref = F.conv2d(x, wt, stride=stride, padding=pad, dilation=dil) * torch.from_numpy(scale).view(1, -1, 1, 1) + torch.from_numpy(shift).view(1, -1, 1, 1)
+    res = None
+    if with_res:
+        res = _r16(rng.normal(0, 1, tuple(ref.shape)))
+        ref = ref + res
+    ref = {None: lambda t: t, "relu": F.relu, "gelu": F.gelu, "sigmoid": torch.sigmoid, "softplus": F.softplus}[act](ref).numpy()
+    got = engf16.conv2d(x.numpy(), wt.numpy(), scale=scale, shift=shift, res=None if res is None else res.numpy(), stride=stride, pad=pad, dil=dil, act=act)
+    assert got.shape == ref.shape
+    # the 2-byte epilogues use the tanh form of GELU (<= 4.8e-4 from the erf form, fe_common.h fe_gelu_fast)
+    tol = 2.0 ** -11 * np.abs(ref) + (6e-4 if act == "gelu" else 2e-4) * np.abs(ref).max()
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f"{int(bad.sum())} of {bad.size} outside tolerance, worst {np.abs(got - ref).max():.3e} (max|ref| {np.abs(ref).max():.3e})"
+
+
+def test_f16_integer_data_is_exact(engf16):
+    """Small integers are exact in fp16 (up to 2048) and their sums exact in fp32: an indexing mistake shows up as a wrong integer."""
+    rng = np.random.default_rng(5)
+    for cin, cout in ((32, 40), (16, 8), (96, 64), (64, 192)):
+        x = rng.integers(-1, 2, (2, cin, 11, 14)).astype(np.float32)
+        w = rng.integers(-1, 2, (cout, cin, 3, 3)).astype(np.float32)
+        ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1).numpy()
+        assert np.abs(ref).max() < 2048
+        got = engf16.conv2d(x, w, pad=1)
+        assert np.array_equal(got, ref), (cin, cout, float(np.abs(got - ref).max()))
+
+
+def test_f16_stores_saturate_instead_of_overflowing(engf16):
+    """fp16 ends at 65504: a layer whose fp32 result lies beyond it stores +-65504, never an infinity (fe_common.h fe_to_f16) - narrow
+    tile (Cout 64), wide tile (Cout 256, K 256) and the scalar epilogue (Cout 20)."""
+    for cin, cout in ((64, 64), (256, 256), (64, 20)):
+        x = np.full((1, cin, 9, 9), 60.0, np.float32)
+        w = np.full((cout, cin, 1, 1), 40.0, np.float32)
+        w[1::2] = -40.0
+        got = engf16.conv2d(x, w)
+        assert np.isfinite(got).all()
+        assert (got[:, 0::2] == 65504.0).all() and (got[:, 1::2] == -65504.0).all()

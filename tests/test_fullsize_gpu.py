@@ -104,10 +104,8 @@ def test_microbatch_past_4gib_tensors_matches_microbatch_32():
         e.set_microbatch(32)
         a = e.topiq_score((d, 66, 1024, 1024))
         e.set_microbatch(64)
-        e.timer_start(); b = e.topiq_score((d, 66, 1024, 1024)); ms = e.timer_stop()
+        b = e.topiq_score((d, 66, 1024, 1024))
         e.dev_free(d)
-        print(f"[micro-batch 64] 66 images in {ms:.0f} ms = {66 / ms * 1e3:.0f} images/s")
-        assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max(), float(np.abs(a - b).max())
-        assert 66 / ms * 1e3 > 370          # through the register-staged fallback those layers used to take, this forward ran at 340 images/s
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max(), float(np.abs(a - b).max())      # throughput of this case: tools/check_large_microbatch.py
     finally:
         e.close()

@@ -132,16 +132,22 @@ from facet_amd.weights import synthetic_state_dict, synthetic_images
 from facet_amd.sharding import shard_range, score_shard
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 N, H, W = int(os.environ["FACET_N"]), 160, 192
-torch.cuda.set_device(0)
+backend = os.environ.get("FACET_BACKEND", "gloo")
+DEV = rank if backend == "nccl" else 0       # gloo: two ranks share the one GPU of the test box; nccl (= RCCL): one GPU per rank
+torch.cuda.set_device(DEV)
 if world > 1:
-    dist.init_process_group("gloo")          # two ranks share the one GPU of the test box; the real run is nccl, one GPU per rank
-eng = Engine(0, arena_bytes=6 << 30, precision=os.environ.get("FACET_PREC", "f32"))
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", DEV))
+    else:
+        dist.init_process_group("gloo")
+side = torch.cuda.Stream(DEV) if os.environ.get("FACET_SIDE_STREAM") else None      # score_shard under a non-default torch stream
+eng = Engine(DEV, arena_bytes=6 << 30, precision=os.environ.get("FACET_PREC", "f32"))
 for mid, name in ((FE_MODEL_TOPIQ, "topiq"), (FE_MODEL_CLIP, "clip"), (FE_MODEL_AESTHETIC, "aesthetic"), (FE_MODEL_U2NETP, "u2netp"),
                   (FE_MODEL_SAMP, "samp_net")):
     eng.load_weights(mid, synthetic_state_dict(name, 13))
 # the sharded ranks keep the face graphs on a second context that runs beside the ensemble (score_shard face_engine, what bench.py
 # does); the single rank runs them on the one context, after the ensemble: the rows must not depend on that
-feng = Engine(0, arena_bytes=2 << 30) if world > 1 else eng
+feng = Engine(DEV, arena_bytes=2 << 30) if world > 1 else eng
 feng.graph_load(FE_GRAPH_FACE_DET, SO.scrfd_like(seed=12, size=160)[0])
 feng.graph_load(FE_GRAPH_FACE_LMK, SO.landmark_like(seed=13)[0])
 feng.graph_load(FE_GRAPH_FACE_REC, SO.arcface_iresnet(layers=(1, 1, 1, 1), seed=14)[0])
@@ -151,7 +157,9 @@ lo, hi = shard_range(N, world, rank)
 d = eng.dev_alloc(max(1, hi - lo) * H * W * 3)
 if hi > lo:
     eng.h2d(d, imgs[lo:hi])
-rec, mask = score_shard(eng, (d, hi - lo, H, W), N, world, rank, faces=((160, 160), 0.3, 0.4, 2), face_engine=feng)
+with (torch.cuda.stream(side) if side is not None else torch.cuda.device(DEV)):
+    for _ in range(2 if side is not None else 1):      # twice under the side stream: the second step reuses the cached ShardBuffers
+        rec, mask = score_shard(eng, (d, hi - lo, H, W), N, world, rank, faces=((160, 160), 0.3, 0.4, 2), face_engine=feng)
 np.save(os.path.join(os.environ["FACET_OUT"], f"rec_w{world}_r{rank}.npy"), rec)
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
@@ -163,18 +171,28 @@ print(json.dumps({"rank": rank, "shape": list(rec.shape), "mask": mask}))
 '''
 
 
-@pytest.mark.parametrize("n_items,prec", [(6, "f32"), (5, "f32"), (5, "bf16")])
-def test_two_ranks_score_their_shards_and_gather_the_single_rank_result(tmp_path, n_items, prec):
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()      # counting devices does not initialise the GPU in this process
+
+
+@pytest.mark.parametrize("n_items,prec,backend", [(6, "f32", "gloo"), (5, "f32", "gloo"), (5, "bf16", "gloo"), (1, "f32", "gloo"),
+                                                   (5, "f32", "nccl")])
+def test_two_ranks_score_their_shards_and_gather_the_single_rank_result(tmp_path, n_items, prec, backend):
     """Engine-level N > 1 run: two fresh processes (gloo, both on GPU 0) each score their shard_range block through
     fe_ensemble_score_dev + fe_face_analyze, all-gather the fixed-size records (789 + 1 + 2 x 739 floats) and must end up with
     exactly the rows a single rank computes for the whole batch - also for a ragged N (5 = 3 + 2), and with the models committed in
-    bf16 (BASELINE configs[3]: the 16gb profile in bf16 sharded across ranks; the face graphs stay fp32)."""
+    bf16 (BASELINE configs[3]: the 16gb profile in bf16 sharded across ranks; the face graphs stay fp32). n_items = 1: rank 1's shard is
+    empty - it still joins the collective and reports the same mask. backend nccl: the RCCL branch proper (one GPU per rank, records
+    gathered device to device); needs two visible GPUs and is skipped on a one-GPU box."""
+    if backend == "nccl" and _gpu_count() < 2:
+        pytest.skip(f"the RCCL (nccl) branch needs 2 visible GPUs, this box has {_gpu_count()}")
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     base.update(FACET_ROOT=ROOT, FACET_OUT=str(tmp_path), FACET_N=str(n_items), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                HSA_ENABLE_IPC_MODE_LEGACY="0", FACET_PREC=prec)
+                HSA_ENABLE_IPC_MODE_LEGACY="0", FACET_PREC=prec, FACET_BACKEND=backend)
     one = subprocess.run([sys.executable, str(script)], env=dict(base, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(base, RANK=str(r), WORLD_SIZE="2"), stdout=subprocess.PIPE,
@@ -193,3 +211,24 @@ def test_two_ranks_score_their_shards_and_gather_the_single_rank_result(tmp_path
     assert np.abs(r0 - single).max() <= tol * max(1.0, np.abs(single).max()), float(np.abs(r0 - single).max())
     assert np.array_equal(r0[:, FE_RECORD_FLOATS], single[:, FE_RECORD_FLOATS])      # face counts
     assert json.loads(one.stdout.strip().splitlines()[-1])["mask"] == 7
+    for so, _ in outs:                                   # also the rank whose shard is empty (n_items < world)
+        assert json.loads(so.strip().splitlines()[-1])["mask"] == 7
+
+
+def test_score_shard_under_a_non_default_torch_stream(tmp_path):
+    """the record table is filled by torch (current stream) and written by the engine (its own non-blocking stream). One
+    rank scores the batch with a side stream current - twice, so the second step runs on the cached buffers - and must reproduce the
+    default-stream rows exactly (ShardBuffers' docstring states the ordering that guarantees it)."""
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base.update(FACET_ROOT=ROOT, FACET_N="3", HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", WORLD_SIZE="1")
+    rows = []
+    for tag, extra in (("plain", {}), ("side", {"FACET_SIDE_STREAM": "1"})):
+        out = tmp_path / tag
+        out.mkdir()
+        r = subprocess.run([sys.executable, str(script)], env=dict(base, FACET_OUT=str(out), **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        rows.append(np.load(out / "rec_w1_r0.npy"))
+    assert rows[0].shape[0] == 3 and np.abs(rows[0][:, 0]).min() > 0
+    assert np.array_equal(rows[0], rows[1])
