@@ -64,6 +64,7 @@ SIGNATURES = {
     "fe_flops_reset": (C.c_int, [C.c_void_p]),
     "fe_flops_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "fe_flops_get_executed": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "fe_flops_get_half": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "fe_weights_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "fe_weights_set": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, _f32p, _i64p, C.c_int]),
     "fe_weights_commit": (C.c_int, [C.c_void_p, C.c_int]),
@@ -275,6 +276,12 @@ class Engine:
     def flops_executed(self):
         f = C.c_double()
         self._ck(self.lib.fe_flops_get_executed(self.h, C.byref(f)))
+        return f.value
+
+    def flops_half(self):
+        """The part of flops() issued on the 2-byte (bf16 / fp16) matrix instructions."""
+        f = C.c_double()
+        self._ck(self.lib.fe_flops_get_half(self.h, C.byref(f)))
         return f.value
 
     def flops_reset(self):

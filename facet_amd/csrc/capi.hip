@@ -3,6 +3,7 @@
 #include <thread>
 
 #include "engine.h"
+#include <type_traits>
 #include "lines_host.h"
 #include "onnx_graph.h"
 #include <algorithm>
@@ -259,6 +260,13 @@ int fe_flops_reset(fe_ctx* ctx) {
   FE_API_BEGIN(ctx)
   ctx->c.flops_accum = 0.0;
   ctx->c.flops_saved = 0.0;
+  ctx->c.flops_half = 0.0;
+  FE_API_END(ctx)
+}
+int fe_flops_get_half(fe_ctx* ctx, double* flops) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(flops, "bad arguments");
+  *flops = ctx->c.flops_half;
   FE_API_END(ctx)
 }
 int fe_flops_get_executed(fe_ctx* ctx, double* flops) {
@@ -541,6 +549,24 @@ int fe_op_conv2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, const 
     ConvOptsT<E> o;
     o.sh = o.sw = stride; o.ph = o.pw = pad; o.dh = o.dw = dil; o.act = act; o.res_after_act = res_after_act;
     TensorT<E> rt;
+    if (C.res32) {
+      // FE_PRECISION_RES32: the fp32-stream form of the layer - residual read as fp32, result written both as fp32 rows (returned)
+      // and as 2-byte rows, which must be the rounding of the fp32 ones (checked here: this entry point is the kernels' test hook)
+      Tensor r32, y32 = C.arena.tensor(n, ho, wo, cout);
+      if (res) { r32 = upload_nchw(C, res, n, cout, ho, wo, cout); o.res32 = &r32; }
+      o.y32 = &y32;
+      TensorT<E> yt = C.arena.tensor_t<E>(n, ho, wo, cout);
+      conv_forward(C, cw, xt, yt, o);
+      download_nchw(C, y32, cout, y);
+      std::vector<float> y16((size_t)n * cout * ho * wo);
+      download_nchw(C, yt, cout, y16.data());
+      for (size_t i = 0; i < y16.size(); ++i) {
+        const float a = std::fmin(std::fmax(y[i], -65504.f), 65504.f);
+        FE_CHECK(std::fabs(y16[i] - a) <= std::fabs(a) * (PrecOf<E>::value == PREC_F16 ? 4.9e-4f : 3.95e-3f) + 6.2e-5f,
+                 "fe_op_conv2d(res32): 2-byte output %g is not the rounding of the fp32 output %g at %zu", y16[i], y[i], i);
+      }
+      return;
+    }
     if (res) { rt = upload_nchw<E>(C, res, n, cout, ho, wo, cout); o.res = &rt; }
     TensorT<E> yt = conv_new(C, cw, xt, o);
     download_nchw(C, yt, cout, y);
@@ -681,7 +707,7 @@ static void topiq_backbone_chunk(fe_ctx* ctx, const uint8_t* d_rgb, int nb, int 
   }
   Tensor x = C.arena.tensor(nb, h, w, 4);
   launch_u8_to_nhwc4_norm(d_rgb, x.p, (size_t)nb * h * w, kImagenetMean, kImagenetStd, 0, C.stream);
-  resnet_forward<T>(C, ctx->c.topiq->backbone, x, &feats);
+  resnet_forward<T>(C, ctx->c.topiq->backbone, x, &feats, ctx->c.topiq->dw.res32);      // RES32: fp32 skip stream in the backbone
 }
 // backbone + head of one micro-batch in the precision the model was committed under; scores are fp32 either way
 static void topiq_chunk_score(fe_ctx* ctx, const uint8_t* d_in, int nb, int h, int w, float* d_scores) {
@@ -787,22 +813,30 @@ extern "C++" {
 // committed under. d_sal (nullable): fp32 device [n][h][w] copy of the saliency map.
 static void samp_chunk(fe_ctx* ctx, const Tensor& x, bool with_samp, float* pw, float* at, float* sd, float* d_sal) {
   Ctx& C = ctx->c;
+  // the two networks may be committed under different precisions (the saliency map crosses in U2-Net-P's type)
+  auto samp_on = [&](auto sal) {
+    typedef decltype(sal.p) SP;
+    typedef std::remove_pointer_t<SP> TS;
+    if (!with_samp) return;
+    if (C.samp->dw.prec == PREC_BF16) sampnet_forward<bf16, TS>(C, *C.samp, x, sal, pw, at, sd);
+    else if (C.samp->dw.prec == PREC_F16) sampnet_forward<f16, TS>(C, *C.samp, x, sal, pw, at, sd);
+    else sampnet_forward<float, TS>(C, *C.samp, x, sal, pw, at, sd);
+  };
   const int prec = C.u2netp->dw.prec;
-  FE_CHECK(!with_samp || C.samp->dw.prec == prec, "u2netp and samp_net were committed under different precisions");
   if (prec == PREC_BF16) {
     TensorH sal = C.arena.tensor_t<bf16>(x.n, x.h, x.w, 1);
     u2netp_forward<bf16>(C, *C.u2netp, x, sal);
-    if (with_samp) sampnet_forward<bf16>(C, *C.samp, x, sal, pw, at, sd);
+    samp_on(sal);
     if (d_sal) launch_convert(sal.p, d_sal, sal.numel(), C.stream);
   } else if (prec == PREC_F16) {
     TensorF16 sal = C.arena.tensor_t<f16>(x.n, x.h, x.w, 1);
     u2netp_forward<f16>(C, *C.u2netp, x, sal);
-    if (with_samp) sampnet_forward<f16>(C, *C.samp, x, sal, pw, at, sd);
+    samp_on(sal);
     if (d_sal) launch_convert(sal.p, d_sal, sal.numel(), C.stream);
   } else {
     Tensor sal = C.arena.tensor(x.n, x.h, x.w, 1);
     u2netp_forward<float>(C, *C.u2netp, x, sal);
-    if (with_samp) sampnet_forward<float>(C, *C.samp, x, sal, pw, at, sd);
+    samp_on(sal);
     if (d_sal) FE_HIP(hipMemcpyAsync(d_sal, sal.p, sal.numel() * sizeof(float), hipMemcpyDeviceToDevice, C.stream));
   }
 }
@@ -884,8 +918,9 @@ static int clip_tower_chunk(const ClipModel& m, int n) {
   return best;
 }
 static void clip_tower(Ctx& C, const Tensor& x, float* feat) {   // in the precision the tower was committed under
-  if (C.clip->dw.prec == PREC_BF16) clip_forward<bf16>(C, *C.clip, x, feat);
-  else if (C.clip->dw.prec == PREC_F16) clip_forward<f16>(C, *C.clip, x, feat);
+  const bool r32 = C.clip->dw.res32;      // fp32 token stream around the 2-byte GEMMs
+  if (C.clip->dw.prec == PREC_BF16) { if (r32) clip_forward<bf16, float>(C, *C.clip, x, feat); else clip_forward<bf16>(C, *C.clip, x, feat); }
+  else if (C.clip->dw.prec == PREC_F16) { if (r32) clip_forward<f16, float>(C, *C.clip, x, feat); else clip_forward<f16>(C, *C.clip, x, feat); }
   else clip_forward<float>(C, *C.clip, x, feat);
 }
 class ClipBatcher {

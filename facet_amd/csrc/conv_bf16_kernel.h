@@ -150,6 +150,103 @@ __device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const C
   }
 }
 
+// The wide epilogue of the fp32-stream forms (FE_PRECISION_RES32: the residual / skip stream of the network stays fp32 around 2-byte
+// GEMM operands). The residual is read as fp32 quads (p.res32; a null residual is an empty buffer - zeros - so one code path serves
+// both), the result leaves as fp32 rows (p.y32) and, with OUT == 2, also as 2-byte rows (p.y: the operand of the next layer's
+// GEMM; the ResNet skip stream needs both, the ViT token stream only fp32 - its 2-byte copy is written by the LayerNorm that
+// follows). Same register layout and LDS staging as h_epilogue_wide: the 2-byte image of the whole wave tile first, then the fp32
+// values one 32-column block at a time through the same wave-private region (144 bytes per row either way), 16-byte stores, eight
+// lanes per 128-byte row segment. ACTK: 0 none, 1 ReLU, -1 named by p.act. No gate, no pad_store.
+template <class E, int TM, int TN, int ACTK, int OUT>
+__device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const ConvParamsT<E>& p, const int row0, const int col0,
+                                                  const int lane, char* const stage) {
+  static_assert(TN == 2, "wide tiles");
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  constexpr int PITCH = TN * 64 + 16;
+  const int r = lane & 31, h = lane >> 5;
+  const int mb = row0 + r, cb = col0 + 4 * h;
+  const bool hs = p.scale != nullptr, hb = p.shift != nullptr;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y ? p.y : const_cast<E*>(p.x), 0, p.y ? (int)p.y_span : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry32 = __builtin_amdgcn_make_buffer_rsrc(p.y32, 0, (int)p.y32_span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res32 ? p.res32 : p.y32), 0, p.res32 ? (int)p.r32_span : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hs ? p.scale : p.y32), 0, hs ? p.Cout * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb ? p.shift : p.y32), 0, hb ? p.Cout * 4 : 0, 0x00020000);
+  bool rok[TM];
+  unsigned rbo[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mb + 32 * i;
+    rok[i] = m < p.M;
+    rbo[i] = (unsigned)m * (unsigned)(p.ldr32 * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c0 = cb + 32 * j + 8 * g;
+      const unsigned co = c0 < p.Cout ? (unsigned)c0 * 4u : OOB;
+      const h_v4 sc = __builtin_bit_cast(h_v4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)co, 0, 0));
+      const h_v4 sf = __builtin_bit_cast(h_v4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)co, 0, 0));
+      h_v4 rv[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        rv[i] = __builtin_bit_cast(h_v4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)((rok[i] && c0 < p.Cout) ? rbo[i] + (unsigned)c0 * 4u : OOB), 0, 0));
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[i][j][4 * g + e] * (hs ? sc[e] : 1.f) + sf[e];
+          if (!p.res_after_act) x += rv[i][e];
+          if (ACTK == 1) x = x > 0.f ? x : 0.f;
+          else if (ACTK < 0) x = fe_apply_act_fast(x, p.act);
+          if (p.res_after_act) x += rv[i][e];
+          v[e] = x;
+          acc[i][j][4 * g + e] = x;          // kept for the fp32 pass below
+        }
+        if (OUT == 2) {
+          h_v2u o;
+          o.x = fe_pack2((const E*)nullptr, v[0], v[1]); o.y = fe_pack2((const E*)nullptr, v[2], v[3]);
+          *reinterpret_cast<h_v2u*>(stage + (32 * i + r) * PITCH + (32 * j + 8 * g + 4 * h) * 2) = o;
+        }
+      }
+    }
+  }
+  if (OUT == 2) {
+    constexpr int LPR = TN * 4, RPI = 64 / LPR;
+    const int lr = lane / LPR, lc = lane % LPR;
+    const int c = col0 + lc * 8;
+#pragma unroll
+    for (int it = 0; it < TM * 32 / RPI; ++it) {
+      const int row = it * RPI + lr, m = row0 + row;
+      const h_v4 d = *reinterpret_cast<const h_v4*>(stage + row * PITCH + lc * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h_v4u, d), ry, (int)((m < p.M && c < p.Cout) ? (unsigned)m * (unsigned)(p.ldy * 2) + (unsigned)c * 2u : OOB), 0, 0);
+    }
+  }
+  // fp32 rows: one 32-column block of the wave tile at a time through the same staging region
+  const int lr = lane >> 3, lc = lane & 7;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads of the previous pass have retired before its image is overwritten
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h_v4 q;
+        q[0] = acc[i][j][4 * g]; q[1] = acc[i][j][4 * g + 1]; q[2] = acc[i][j][4 * g + 2]; q[3] = acc[i][j][4 * g + 3];
+        *reinterpret_cast<h_v4*>(stage + (32 * i + r) * PITCH + (8 * g + 4 * h) * 4) = q;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int c = col0 + 32 * j + lc * 4;
+#pragma unroll
+    for (int it = 0; it < TM * 4; ++it) {
+      const int row = it * 8 + lr, m = row0 + row;
+      const h_v4 d = *reinterpret_cast<const h_v4*>(stage + row * PITCH + lc * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h_v4u, d), ry32, (int)((m < p.M && c < p.Cout) ? (unsigned)m * (unsigned)(p.ldy32 * 4) + (unsigned)c * 4u : OOB), 0, 0);
+    }
+  }
+}
+
 // UNITS = 32 / cb: (channel block, tap) units per 32-element slab. MODE 0 plain, 2 PReLU epilogue.
 // ONE_TAP: 1x1 kernels (GEMMs) - no tap masks, the K offset of a slab goes into the scalar offset of the buffer load.
 template <class E, int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
@@ -286,7 +383,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
       // straight-line forms of the combinations the models use; the rest (softplus gates, residual after the activation) take the
       // form that reads activation, gate and residual order from the parameters
       const bool plain = !p.gate && !(p.res && p.res_after_act);
-      if (plain && p.act == ACT_NONE) {
+      if (p.y32) {      // fp32-stream forms (launch_conv_bf16 admits them only without gate / E-typed residual / pad_store)
+        if (!p.y && p.act == ACT_NONE && !p.res_after_act) h_epilogue_wide32<E, TM, TN, 0, 1>(acc, p, row0, col0, lane, stage);        // ViT projections
+        else if (p.y && p.act == ACT_RELU && !p.res_after_act) h_epilogue_wide32<E, TM, TN, 1, 2>(acc, p, row0, col0, lane, stage);    // ResNet block outputs
+        else h_epilogue_wide32<E, TM, TN, -1, 2>(acc, p, row0, col0, lane, stage);      // anything else (a null p.y is an empty buffer: stores dropped)
+      } else if (plain && p.act == ACT_NONE) {
         if (p.res) h_epilogue_wide<E, TM, TN, 0, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<E, TM, TN, 0, false, false>(acc, p, row0, col0, lane, stage);
       } else if (plain && p.act == ACT_RELU) {
         if (p.res) h_epilogue_wide<E, TM, TN, 1, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<E, TM, TN, 1, false, false>(acc, p, row0, col0, lane, stage);
@@ -515,6 +616,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           for (int e = 0; e < 16; ++e) Et[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
         const int mrow0 = m0 + wm * TM * 32 + i * 32 + lr;
         uint4 rv[NIT];
+        float4 r32a[NIT], r32b[NIT];      // fp32 residual rows (FE_PRECISION_RES32 streams)
         float gs[NIT];
         uint4 gv[NIT];
   #pragma unroll
@@ -523,6 +625,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           const int mc = m < p.M ? m : p.M - 1;
           if constexpr (RES_AHEAD) { if (p.res) rv[it] = rall[i * NIT + it]; }
           else if (p.res) rv[it] = *reinterpret_cast<const uint4*>(p.res + (size_t)mc * p.ldr + colc);
+          if (p.res32) {
+            r32a[it] = *reinterpret_cast<const float4*>(p.res32 + (size_t)mc * p.ldr32 + colc);
+            r32b[it] = *reinterpret_cast<const float4*>(p.res32 + (size_t)mc * p.ldr32 + colc + 4);
+          }
           if (p.gate) {
             if (p.gate_c1) gs[it] = (float)p.gate[(size_t)mc * p.ldg];
             else gv[it] = *reinterpret_cast<const uint4*>(p.gate + (size_t)mc * p.ldg + colc);
@@ -535,15 +641,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           const float4 v1 = *reinterpret_cast<const float4*>(&Et[(lr + it * RPI) * ES + lc + 4]);
           float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
           float rf[8], gf[8];
+          const bool hres = p.res || p.res32;
           if (p.res) h_unpack8<E>(rv[it], rf);
+          else if (p.res32) {
+            rf[0] = r32a[it].x; rf[1] = r32a[it].y; rf[2] = r32a[it].z; rf[3] = r32a[it].w;
+            rf[4] = r32b[it].x; rf[5] = r32b[it].y; rf[6] = r32b[it].z; rf[7] = r32b[it].w;
+          }
           if (p.gate && !p.gate_c1) h_unpack8<E>(gv[it], gf);
   #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float x = v[e] * sc[e] + sf[e];
-            if (p.res && !p.res_after_act) x += rf[e];
+            if (hres && !p.res_after_act) x += rf[e];
             if constexpr (MODE == 2) x = x > 0.f ? x : x * sl[e];
             else x = fe_apply_act_fast(x, p.act);
-            if (p.res && p.res_after_act) x += rf[e];
+            if (hres && p.res_after_act) x += rf[e];
             if (p.gate) x *= p.gate_c1 ? gs[it] : gf[e];
             if (!cfull && colb + e >= p.Cout) x = 0.f;
             v[e] = x;
@@ -551,7 +662,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           H8 o;
           o.u = make_uint4(fe_pack2((const E*)nullptr, v[0], v[1]), fe_pack2((const E*)nullptr, v[2], v[3]),
                            fe_pack2((const E*)nullptr, v[4], v[5]), fe_pack2((const E*)nullptr, v[6], v[7]));
-          if (cok && m < p.M) *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + colb) = o.u;
+          if (cok && m < p.M) {
+            if (p.y) *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + colb) = o.u;
+            if (p.y32) {      // (vec_epi with an fp32 output: Cout % 8 == 0, no pad_store)
+              *reinterpret_cast<float4*>(p.y32 + (size_t)m * p.ldy32 + colb) = make_float4(v[0], v[1], v[2], v[3]);
+              *reinterpret_cast<float4*>(p.y32 + (size_t)m * p.ldy32 + colb + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+          }
         }
       }
       return;
@@ -571,12 +688,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           const int m = m0 + row;
           if (cok && m < p.M) {
             float v = acc[i][j][e] * sc + sf;
-            if (p.res && !p.res_after_act) v += (float)p.res[(size_t)m * p.ldr + col];
+            const float rs_ = p.res ? (float)p.res[(size_t)m * p.ldr + col] : (p.res32 ? p.res32[(size_t)m * p.ldr32 + col] : 0.f);
+            if (!p.res_after_act) v += rs_;
             if constexpr (MODE == 2) v = v > 0.f ? v : v * p.slope[col];
             else v = fe_apply_act(v, p.act);
-            if (p.res && p.res_after_act) v += (float)p.res[(size_t)m * p.ldr + col];
+            if (p.res_after_act) v += rs_;
             if (p.gate) v *= (float)p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
-            stf(&p.y[(size_t)m * p.ldy + col], v);
+            if (p.y) stf(&p.y[(size_t)m * p.ldy + col], v);
+            if (p.y32) p.y32[(size_t)m * p.ldy32 + col] = v;
           }
         }
       }

@@ -109,9 +109,10 @@ MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& pref
 // The layer wrappers below exist for T = float (fp32 path) and T = bf16 (models committed under PREC_BF16): same call shapes,
 // overloads / explicit instantiations in engine.hip.
 // y[B*Lq][d] = res + out_proj(softmax(q k^T / sqrt(hd)) v); q from q_in, k/v from kv_in (rows = tokens).
-template <class T>
+// RT = type of the residual / output rows: T, or float around 2-byte projections (fp32 token stream, FE_PRECISION_RES32)
+template <class T, class RT>
 void mha_forward(Ctx& c, const MHAW& m, const T* q_in, int ldq, const T* kv_in, int ldkv, int B, int Lq,
-                 int Lk, const T* res, int ldr, T* y, int ldy, bool causal = false);
+                 int Lk, const RT* res, int ldr, RT* y, int ldy, bool causal = false);
 // y[M][N] = act(x[M][K] W^T + b) (+res)
 void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act,
                     const float* res = nullptr, int ldr = 0);
@@ -119,10 +120,22 @@ void linear_forward(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16*
                     const bf16* res = nullptr, int ldr = 0);
 void linear_forward(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, f16* y, int ldy, int act,
                     const f16* res = nullptr, int ldr = 0);
+// 2-byte operand rows, fp32 residual rows (nullable) and fp32 result rows (the projections that write an fp32 token stream)
+void linear_forward_s32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float* y, int ldy, int act, const float* res = nullptr, int ldr = 0);
+void linear_forward_s32(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, float* y, int ldy, int act, const float* res = nullptr, int ldr = 0);
+// y = act(x W^T + b) + res with y / res of the caller's stream type: (T, T) = linear_forward, (2-byte, float) = linear_forward_s32
+void linear_forward_res(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act, const float* res, int ldr);
+void linear_forward_res(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16* y, int ldy, int act, const bf16* res, int ldr);
+void linear_forward_res(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, f16* y, int ldy, int act, const f16* res, int ldr);
+void linear_forward_res(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float* y, int ldy, int act, const float* res, int ldr);
+void linear_forward_res(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, float* y, int ldy, int act, const float* res, int ldr);
 // same with fp32 outputs whatever the activation type (the last layer of a head: scores / features leave the engine in fp32)
 void linear_forward_f32(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act);
 void linear_forward_f32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float* y, int ldy, int act);
 void linear_forward_f32(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, float* y, int ldy, int act);
+// fp32 rows in, fp32 rows out, on the 2-byte copy of the weights (type `prec` = the model's): weight rows streamed once per 32 rows,
+// activations never rounded (per-image head vectors of a FE_PRECISION_RES32 model)
+void linear_forward_xf32(Ctx& c, const ConvW& w, int prec, const float* x, int ldx, int M, float* y, int ldy, int act);
 template <class T>
 inline TensorT<T> mat_view(const T* p, int rows, int cols, int ld) {
   TensorT<T> t; t.p = const_cast<T*>(p); t.n = 1; t.h = 1; t.w = rows; t.c = cols; t.ld = ld; return t;
@@ -157,8 +170,11 @@ struct ResNet {
 void build_resnet(ResNet& r, DeviceWeights& dw, const WeightStore& ws, const std::string& prefix,
                   bool bottleneck, const int blocks[4], bool seq_names);
 // feats (optional) receives [stem-relu, layer1..layer4]; returns layer4 output. x is always the fp32 NHWC4 image tensor.
+// res32 (2-byte T only; FE_PRECISION_RES32): the skip stream of the network is kept in fp32 - every block's output leaves its
+// last convolution both as fp32 (the next block's identity / the downsample branch's output) and as T (the operand of the next
+// convolutions); last32 (optional) receives the fp32 form of the returned map.
 template <class T>
-TensorT<T> resnet_forward(Ctx& c, const ResNet& r, const Tensor& x_nhwc4, std::vector<TensorT<T>>* feats);
+TensorT<T> resnet_forward(Ctx& c, const ResNet& r, const Tensor& x_nhwc4, std::vector<TensorT<T>>* feats, bool res32 = false, Tensor* last32 = nullptr);
 
 // ---- PIL-exact uint8 resampling (kernels_resize.hip) --------------------------------------------------
 enum ResizeFilter : int { FE_FILTER_LANCZOS = 1, FE_FILTER_BILINEAR = 2, FE_FILTER_BICUBIC = 3 };  // PIL's enum values
@@ -184,6 +200,8 @@ struct Ctx {
   std::vector<OpTiming> timings;
   double flops_accum = 0.0;
   double flops_saved = 0.0;   // algorithmic FLOPs NOT executed because a layer ran as Winograd (executed = flops_accum - flops_saved)
+  double flops_half = 0.0;    // the part of flops_accum issued on the 2-byte matrix instructions (bf16 / f16 models): a mixed-precision
+                              // run is priced per dtype (bench.py roofline: fp32 FLOPs / fp32 peak + 2-byte FLOPs / 2-byte peak)
   int force_variant = 0;   // developer hook: forwarded to ConvParams.variant
   int precision = PREC_F32;   // what the NEXT fe_weights_commit builds (fe_set_precision); each model remembers its own
   bool res32 = false;         // FE_PRECISION_RES32 of the next commit: fp32 residual streams around 2-byte GEMM operands
@@ -246,8 +264,9 @@ void build_sampnet(SampModel& m, const WeightStore& ws);
 // T = activation type (float | bf16); x_nhwc4 is always the fp32 pixel tensor, the score outputs are always fp32
 template <class T>
 void u2netp_forward(Ctx& c, const U2NetPModel& m, const Tensor& x_nhwc4, const TensorT<T>& sal);
-template <class T>
-void sampnet_forward(Ctx& c, const SampModel& m, const Tensor& x_nhwc4, const TensorT<T>& sal, float* pw, float* attrs,
+// TS = element type of the saliency map (U2-Net-P may be committed under another precision than SAMP-Net)
+template <class T, class TS>
+void sampnet_forward(Ctx& c, const SampModel& m, const Tensor& x_nhwc4, const TensorT<TS>& sal, float* pw, float* attrs,
                      float* dist);
 
 // ---- CLIP ViT image tower + aesthetic MLP -------------------------------------------------------------
@@ -276,7 +295,9 @@ void build_clip_text(ClipTextModel& m, const WeightStore& ws);
 void clip_text_forward(Ctx& c, const ClipTextModel& m, const int* tokens, const int* eot, int B, float* feat);
 void build_clip(ClipModel& m, const WeightStore& ws);
 void build_aesthetic(AestheticModel& m, const WeightStore& ws);
-template <class T>   // T: activation type of the tower; input pixels and output features are fp32 either way
+// T: type of the GEMM operands of the tower (float | bf16 | f16); RT: type of the token (residual) stream and of every LayerNorm
+// input - T, or float under FE_PRECISION_RES32; input pixels and output features are fp32 either way
+template <class T, class RT = T>
 void clip_forward(Ctx& c, const ClipModel& m, const Tensor& x_nhwc4, float* feat);
 void aesthetic_forward(Ctx& c, const AestheticModel& m, const float* feat, int B, float* raw);
 void l2_normalize(Ctx& c, const float* x, float* y, int rows, int d);

@@ -424,6 +424,7 @@ static void conv_forward_half(Ctx& c, const ConvW& w, const TensorT<E>& x, const
            "precision, or a 3-channel first layer)");
   FE_CHECK(x.c == w.CinPadH, "conv(bf16): input channels %d != packed Cin %d", x.c, w.CinPadH);
   FE_CHECK(y.c == w.Cout && y.n == x.n, "conv(bf16): output view mismatch (c=%d Cout=%d)", y.c, w.Cout);
+  FE_CHECK(y.p || o.y32, "conv(2-byte): no output tensor");
   FE_CHECK(y.h == conv_out_dim(x.h, w.KH, o.sh, o.ph, o.dh) && y.w == conv_out_dim(x.w, w.KW, o.sw, o.pw, o.dw),
            "conv(bf16): output dims %dx%d inconsistent with input %dx%d", y.h, y.w, x.h, x.w);
   FE_CHECK(y.pixels() < (1ull << 31), "conv: M too large");
@@ -436,7 +437,7 @@ static void conv_forward_half(Ctx& c, const ConvW& w, const TensorT<E>& x, const
   ConvParamsT<E> p{};
   p.scale = w.scale; p.shift = w.shift; p.slope = w.slope;
   p.N = x.n; p.H = x.h; p.W = x.w; p.Cin = w.CinPadH; p.x = x.p; p.ldx = x.ld;
-  if (w.wtap_h && o.act != ACT_PRELU && o.sh == 1 && o.sw == 1 && !o.res && !o.gate && y.h == x.h && y.w == x.w) {
+  if (w.wtap_h && o.act != ACT_PRELU && o.sh == 1 && o.sw == 1 && !o.res && !o.gate && !o.res32 && !o.y32 && y.h == x.h && y.w == x.w) {
     // narrow spatial conv (Cout <= 2): 1x1 conv to per-tap partials on the matrix cores + a gather-sum pass (see the fp32 path)
     const int T = w.KH * w.KW * w.Cout, T8 = (T + 7) & ~7;
     const size_t mark = c.arena.mark();
@@ -456,6 +457,14 @@ static void conv_forward_half(Ctx& c, const ConvW& w, const TensorT<E>& x, const
     if (o.gate) {
       FE_CHECK(o.gate->pixels() == y.pixels() && (o.gate->c == 1 || o.gate->c == y.c), "conv: gate shape mismatch");
       p.gate = o.gate->p; p.ldg = o.gate->ld; p.gate_c1 = o.gate->c == 1;
+    }
+    if (o.res32) {
+      FE_CHECK(!o.res && o.res32->c == y.c && o.res32->pixels() == y.pixels(), "conv: fp32 residual shape mismatch");
+      p.res32 = o.res32->p; p.ldr32 = o.res32->ld;
+    }
+    if (o.y32) {
+      FE_CHECK(o.y32->c == y.c && o.y32->pixels() == y.pixels(), "conv: fp32 output shape mismatch");
+      p.y32 = o.y32->p; p.ldy32 = o.y32->ld;
     }
     p.w = (const E*)w.wh; p.y = y.p; p.ldy = y.ld;
     p.Ho = y.h; p.Wo = y.w; p.Cout = w.Cout;
@@ -477,6 +486,7 @@ static void conv_forward_half(Ctx& c, const ConvW& w, const TensorT<E>& x, const
     c.timings.push_back({nm, flops, bytes, ms});
   }
   c.flops_accum += flops;
+  c.flops_half += flops;
 }
 void conv_forward(Ctx& c, const ConvW& w, const TensorH& x, const TensorH& y, const ConvOptsT<bf16>& o) { conv_forward_half<bf16>(c, w, x, y, o); }
 void conv_forward(Ctx& c, const ConvW& w, const TensorF16& x, const TensorF16& y, const ConvOptsT<f16>& o) { conv_forward_half<f16>(c, w, x, y, o); }
@@ -503,6 +513,7 @@ static TensorT<E> first_conv_half(Ctx& c, const ConvW& w, const Tensor& x, const
   if (stem && launch_stem(x.p, x.ld, x.n, x.h, x.w, w.wstem, w.scale, w.shift, w.slope, w.Cout, w.KH, o.sh,
                           o.act == ACT_RELU ? 1 : (o.act == ACT_PRELU ? 2 : 0), y.p, y.ld, ho, wo, c.stream)) {
     c.flops_accum += 2.0 * (double)y.pixels() * (double)(w.KH * w.KW * w.Cin) * w.Cout;
+    if (w.KH == 7) c.flops_half += 2.0 * (double)y.pixels() * (double)(w.KH * w.KW * w.Cin) * w.Cout;      // the 7x7 stems run on the 2-byte matrix cores
     return y;
   }
   // shapes the stem kernel does not take: the fp32 kernel, then one conversion pass
@@ -546,15 +557,58 @@ void build_resnet(ResNet& r, DeviceWeights& dw, const WeightStore& ws, const std
 }
 
 template <class T>
-TensorT<T> resnet_forward(Ctx& c, const ResNet& r, const Tensor& x, std::vector<TensorT<T>>* feats) {
+TensorT<T> resnet_forward(Ctx& c, const ResNet& r, const Tensor& x, std::vector<TensorT<T>>* feats, bool res32, Tensor* last32) {
   ConvOpts so; so.sh = so.sw = 2; so.ph = so.pw = 3; so.act = ACT_RELU;
   TensorT<T> t = first_conv<T>(c, r.stem, x, so);
   if (feats) feats->push_back(t);
   TensorT<T> p = c.arena.tensor_t<T>(t.n, conv_out_dim(t.h, 3, 2, 1, 1), conv_out_dim(t.w, 3, 2, 1, 1), t.c);
   launch_maxpool(t, p, 3, 2, 1, c.stream);
   t = p;
+  Tensor t32;      // fp32 skip stream (res32): the fp32 form of t
+  if constexpr (sizeof(T) == 2) {
+    if (res32) {
+      t32 = c.arena.tensor(t.n, t.h, t.w, t.c);
+      launch_convert(t.p, t32.p, t.numel(), c.stream);
+    }
+  } else {
+    res32 = false;
+  }
   for (size_t li = 0; li < r.layers.size(); ++li) {
     for (const ResBlock& b : r.layers[li]) {
+      if constexpr (sizeof(T) == 2) {
+        if (res32) {
+          // identity in fp32: the stream itself, or the downsample branch written as fp32 only
+          Tensor idt32 = t32;
+          if (b.has_down) {
+            idt32 = c.arena.tensor(t.n, conv_out_dim(t.h, 1, b.stride, 0, 1), conv_out_dim(t.w, 1, b.stride, 0, 1), b.down.Cout);
+            TensorT<T> none = idt32.template retype<T>();
+            ConvOptsT<T> d; d.sh = d.sw = b.stride; d.y32 = &idt32;
+            conv_forward(c, b.down, t, none, d);
+          }
+          TensorT<T> bb;
+          const ConvW* last;
+          if (b.bottleneck) {
+            ConvOptsT<T> o1; o1.act = ACT_RELU;
+            TensorT<T> a = conv_new(c, b.c1, t, o1);
+            ConvOptsT<T> o2; o2.sh = o2.sw = b.stride; o2.ph = o2.pw = 1; o2.act = ACT_RELU;
+            bb = conv_new(c, b.c2, a, o2);
+            last = &b.c3;
+          } else {
+            ConvOptsT<T> o1; o1.sh = o1.sw = b.stride; o1.ph = o1.pw = 1; o1.act = ACT_RELU;
+            bb = conv_new(c, b.c1, t, o1);
+            last = &b.c2;
+          }
+          // block output = relu(conv + identity): fp32 (the stream) and T (the next operand) from one epilogue
+          ConvOptsT<T> o3; o3.act = ACT_RELU; o3.res32 = &idt32;
+          if (!b.bottleneck) o3.ph = o3.pw = 1;
+          TensorT<T> tn = c.arena.tensor_t<T>(bb.n, bb.h, bb.w, last->Cout);
+          Tensor tn32 = c.arena.tensor(bb.n, bb.h, bb.w, last->Cout);
+          o3.y32 = &tn32;
+          conv_forward(c, *last, bb, tn, o3);
+          t = tn; t32 = tn32;
+          continue;
+        }
+      }
       TensorT<T> idt = t;
       if (b.has_down) {
         ConvOptsT<T> d; d.sh = d.sw = b.stride;
@@ -577,11 +631,12 @@ TensorT<T> resnet_forward(Ctx& c, const ResNet& r, const Tensor& x, std::vector<
     }
     if (feats) feats->push_back(t);
   }
+  if (last32) *last32 = t32;
   return t;
 }
-template Tensor resnet_forward<float>(Ctx&, const ResNet&, const Tensor&, std::vector<Tensor>*);
-template TensorH resnet_forward<bf16>(Ctx&, const ResNet&, const Tensor&, std::vector<TensorH>*);
-template TensorF16 resnet_forward<f16>(Ctx&, const ResNet&, const Tensor&, std::vector<TensorF16>*);
+template Tensor resnet_forward<float>(Ctx&, const ResNet&, const Tensor&, std::vector<Tensor>*, bool, Tensor*);
+template TensorH resnet_forward<bf16>(Ctx&, const ResNet&, const Tensor&, std::vector<TensorH>*, bool, Tensor*);
+template TensorF16 resnet_forward<f16>(Ctx&, const ResNet&, const Tensor&, std::vector<TensorF16>*, bool, Tensor*);
 
 }  // namespace fe
 
@@ -622,6 +677,22 @@ static void linear_forward_half(Ctx& c, const ConvW& w, const E* x, int ldx, int
   if (res) { rt = mat_view(res, M, w.Cout, ldr); o.res = &rt; }
   conv_forward(c, w, xt, yt, o);
 }
+// 2-byte operand rows, fp32 residual rows (nullable), fp32 result rows: the projections that write the fp32 token stream
+template <class E>
+static void linear_forward_s32_half(Ctx& c, const ConvW& w, const E* x, int ldx, int M, float* y, int ldy, int act, const float* res, int ldr) {
+  FE_CHECK(w.wh && w.hprec == PrecOf<E>::value, "linear(2-byte): layer has no weights of the activations' type");
+  TensorT<E> xt = mat_view(x, M, w.CinPadH, ldx), yt = mat_view((E*)nullptr, M, w.Cout, 0);
+  Tensor y32 = mat_view(y, M, w.Cout, ldy), r32;
+  ConvOptsT<E> o; o.act = act; o.y32 = &y32;
+  if (res) { r32 = mat_view(res, M, w.Cout, ldr); o.res32 = &r32; }
+  conv_forward(c, w, xt, yt, o);
+}
+void linear_forward_s32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float* y, int ldy, int act, const float* res, int ldr) {
+  linear_forward_s32_half<bf16>(c, w, x, ldx, M, y, ldy, act, res, ldr);
+}
+void linear_forward_s32(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, float* y, int ldy, int act, const float* res, int ldr) {
+  linear_forward_s32_half<f16>(c, w, x, ldx, M, y, ldy, act, res, ldr);
+}
 void linear_forward(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16* y, int ldy, int act, const bf16* res, int ldr) {
   linear_forward_half<bf16>(c, w, x, ldx, M, y, ldy, act, res, ldr);
 }
@@ -640,6 +711,15 @@ static void linear_forward_f32_half(Ctx& c, const ConvW& w, const E* x, int ldx,
 }
 void linear_forward_f32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float* y, int ldy, int act) { linear_forward_f32_half<bf16>(c, w, x, ldx, M, y, ldy, act); }
 void linear_forward_f32(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, float* y, int ldy, int act) { linear_forward_f32_half<f16>(c, w, x, ldx, M, y, ldy, act); }
+void linear_forward_xf32(Ctx& c, const ConvW& w, int prec, const float* x, int ldx, int M, float* y, int ldy, int act) {
+  FE_CHECK(w.wh && w.hprec == prec && act != ACT_PRELU && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "linear_xf32: unsupported layer");
+  for (int m0 = 0; m0 < M; m0 += 32) {
+    const int mb = std::min(32, M - m0);
+    if (prec == PREC_F16) launch_gemm_skinny(x + (size_t)m0 * ldx, ldx, (const f16*)w.wh, w.KpH, w.scale, w.shift, y + (size_t)m0 * ldy, ldy, mb, w.Cout, w.CinPadH, act, c.stream);
+    else launch_gemm_skinny(x + (size_t)m0 * ldx, ldx, (const bf16*)w.wh, w.KpH, w.scale, w.shift, y + (size_t)m0 * ldy, ldy, mb, w.Cout, w.CinPadH, act, c.stream);
+  }
+  c.flops_accum += 2.0 * M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : w.Cout);
+}
 
 MHAW build_mha(DeviceWeights& dw, const WeightStore& ws, const std::string& prefix, int heads) {
   MHAW m;
@@ -702,6 +782,7 @@ static void raw_gemm(Ctx& c, ConvParamsT<T>& p, double flops) {
     c.timings.push_back({nm, flops, 0.0, ms});
   }
   c.flops_accum += flops;
+  if (sizeof(T) == 2) c.flops_half += flops;
 }
 
 static const float* mha_wv(const MHAW& m, const float*) { return m.wv; }
@@ -714,9 +795,16 @@ static const f16* mha_wv(const MHAW& m, const f16*) {
   return (const f16*)m.wv_h;
 }
 
-template <class T>
+// y (+= res) in the stream type RT of the caller: the plain layer when RT is the operand type, the fp32-stream form otherwise
+void linear_forward_res(Ctx& c, const ConvW& w, const float* x, int ldx, int M, float* y, int ldy, int act, const float* res, int ldr) { linear_forward(c, w, x, ldx, M, y, ldy, act, res, ldr); }
+void linear_forward_res(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16* y, int ldy, int act, const bf16* res, int ldr) { linear_forward(c, w, x, ldx, M, y, ldy, act, res, ldr); }
+void linear_forward_res(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, f16* y, int ldy, int act, const f16* res, int ldr) { linear_forward(c, w, x, ldx, M, y, ldy, act, res, ldr); }
+void linear_forward_res(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float* y, int ldy, int act, const float* res, int ldr) { linear_forward_s32(c, w, x, ldx, M, y, ldy, act, res, ldr); }
+void linear_forward_res(Ctx& c, const ConvW& w, const f16* x, int ldx, int M, float* y, int ldy, int act, const float* res, int ldr) { linear_forward_s32(c, w, x, ldx, M, y, ldy, act, res, ldr); }
+
+template <class T, class RT>
 void mha_forward(Ctx& c, const MHAW& m, const T* q_in, int ldq, const T* kv_in, int ldkv, int B, int Lq, int Lk,
-                 const T* res, int ldr, T* y, int ldy, bool causal) {
+                 const RT* res, int ldr, RT* y, int ldy, bool causal) {
   constexpr bool half = sizeof(T) == 2;
   const int d = m.d, H = m.heads, hd = d / H;
   const int Lp = (Lk + 31) / 32 * 32;  // padded key count: row stride of the score matrix and of V^T
@@ -745,6 +833,7 @@ void mha_forward(Ctx& c, const MHAW& m, const T* q_in, int ldq, const T* kv_in, 
     // fused QK^T -> online softmax -> PV (kernels_attn.hip / kernels_attn_bf16.hip); scores never touch HBM
     launch_attention(Q, d, K, d, Vt, Lp, m.bv, O, d, B, H, Lq, Lk, d, causal ? 1 : 0, c.stream);
     c.flops_accum += 4.0 * B * H * (double)Lq * Lk * hd;
+    if (half) c.flops_half += 4.0 * B * H * (double)Lq * Lk * hd;
   } else if constexpr (!half) {
     {  // S[b,h] [Lq][Lk] = Q_bh K_bh^T
       ConvParams p{};
@@ -768,11 +857,13 @@ void mha_forward(Ctx& c, const MHAW& m, const T* q_in, int ldq, const T* kv_in, 
       raw_gemm(c, p, 2.0 * B * H * (double)Lq * Lk * hd);
     }
   }
-  linear_forward(c, m.out, O, d, B * Lq, y, ldy, ACT_NONE, res, ldr);
+  linear_forward_res(c, m.out, (const T*)O, d, B * Lq, y, ldy, ACT_NONE, res, ldr);
   c.arena.rewind(mark);
 }
-template void mha_forward<float>(Ctx&, const MHAW&, const float*, int, const float*, int, int, int, int, const float*, int, float*, int, bool);
-template void mha_forward<bf16>(Ctx&, const MHAW&, const bf16*, int, const bf16*, int, int, int, int, const bf16*, int, bf16*, int, bool);
-template void mha_forward<f16>(Ctx&, const MHAW&, const f16*, int, const f16*, int, int, int, int, const f16*, int, f16*, int, bool);
+template void mha_forward<float, float>(Ctx&, const MHAW&, const float*, int, const float*, int, int, int, int, const float*, int, float*, int, bool);
+template void mha_forward<bf16, bf16>(Ctx&, const MHAW&, const bf16*, int, const bf16*, int, int, int, int, const bf16*, int, bf16*, int, bool);
+template void mha_forward<f16, f16>(Ctx&, const MHAW&, const f16*, int, const f16*, int, int, int, int, const f16*, int, f16*, int, bool);
+template void mha_forward<bf16, float>(Ctx&, const MHAW&, const bf16*, int, const bf16*, int, int, int, int, const float*, int, float*, int, bool);
+template void mha_forward<f16, float>(Ctx&, const MHAW&, const f16*, int, const f16*, int, int, int, int, const float*, int, float*, int, bool);
 
 }  // namespace fe

@@ -123,6 +123,12 @@ struct TensorT {
     t.c = cn;
     return t;
   }
+  // the same shape with a NULL pointer of another element type: the "no 2-byte output" view of a layer that only writes fp32 (ConvOptsT::y32)
+  template <class U> TensorT<U> retype() const {
+    TensorT<U> t;
+    t.p = nullptr; t.n = n; t.h = h; t.w = w; t.c = c; t.ld = c;
+    return t;
+  }
 };
 using Tensor = TensorT<float>;
 using TensorH = TensorT<bf16>;
@@ -228,6 +234,11 @@ struct ConvParamsT {
   int variant;                      // 0 = auto tile choice; >0 forces a tile variant (tools/conv_bench.py)
   int cb;                           // bf16 kernel: channel block of the packed K order (32, or 16 for Cin % 32 != 0 spatial kernels)
   int pad_store;                    // bf16 kernel: columns [Cout, roundup8(Cout)) exist in y and are written as zeros (V^T GEMM)
+  // 2-byte kernels, fp32 streams (FE_PRECISION_RES32): the residual read as fp32 (instead of `res`) and / or the result also written
+  // as fp32 rows; `y` may then be null (fp32 output only). Same N, Ho, Wo, Cout as y.
+  const float* res32; int ldr32;
+  float* y32; int ldy32;
+  unsigned r32_span, y32_span;      // set by launch_conv_bf16: byte spans for buffer addressing
 };
 using ConvParams = ConvParamsT<float>;
 using ConvParamsH = ConvParamsT<bf16>;
@@ -262,6 +273,10 @@ struct ConvOptsT {
   const TensorT<T>* res = nullptr;
   int res_after_act = 0;
   const TensorT<T>* gate = nullptr;
+  // 2-byte layers of a model with fp32 residual streams: residual taken from / result also delivered to an fp32 tensor (the TensorT<T>
+  // output view passed to conv_forward may then carry a null pointer: fp32 output only)
+  const TensorT<float>* res32 = nullptr;
+  const TensorT<float>* y32 = nullptr;
 };
 using ConvOpts = ConvOptsT<float>;
 
@@ -289,7 +304,9 @@ template <class T, class Launch>
 inline bool conv_split_by_images(const ConvParamsT<T>& p, Launch&& launch) {
   if (p.batch > 1 || p.N <= 1 || (long long)p.N * p.Ho * p.Wo != (long long)p.M) return false;
   const unsigned long long in_img = (unsigned long long)p.H * p.W * p.ldx * sizeof(T);
-  const unsigned long long out_img = (unsigned long long)p.Ho * p.Wo * (unsigned long long)(p.ldy > p.ldr ? p.ldy : p.ldr) * sizeof(T);
+  unsigned long long out_img = (unsigned long long)p.Ho * p.Wo * (unsigned long long)(p.ldy > p.ldr ? p.ldy : p.ldr) * sizeof(T);
+  const unsigned long long out32_img = (unsigned long long)p.Ho * p.Wo * (unsigned long long)(p.ldy32 > p.ldr32 ? p.ldy32 : p.ldr32) * sizeof(float);
+  if ((p.y32 || p.res32) && out32_img > out_img) out_img = out32_img;
   const unsigned long long per_img = in_img > out_img ? in_img : out_img;
   constexpr unsigned long long LIMIT = 0xF0000000ull;
   if (per_img >= LIMIT) return false;
@@ -301,7 +318,9 @@ inline bool conv_split_by_images(const ConvParamsT<T>& p, Launch&& launch) {
     const size_t opix = (size_t)i0 * p.Ho * p.Wo;
     q.N = n; q.M = n * p.Ho * p.Wo;
     q.x = p.x + (size_t)i0 * p.H * p.W * p.ldx;
-    q.y = p.y + opix * p.ldy;
+    if (p.y) q.y = p.y + opix * p.ldy;
+    if (p.y32) q.y32 = p.y32 + opix * p.ldy32;
+    if (p.res32) q.res32 = p.res32 + opix * p.ldr32;
     if (p.res) q.res = p.res + opix * p.ldr;
     if (p.gate) q.gate = p.gate + opix * p.ldg;
     launch(q);

@@ -1,6 +1,7 @@
 // 2-byte (bf16 / fp16) implicit-GEMM convolution: tile policy, launcher and the narrow-tile instantiations (kernel: conv_bf16_kernel.h).
 // FE_E = element type of this translation unit: bf16 here, f16 through kernels_conv_f16.hip, which includes this file.
 #include "conv_bf16_kernel.h"
+#include <algorithm>
 #ifndef FE_E
 #define FE_E bf16
 #endif
@@ -37,7 +38,11 @@ static void launch_bf16_tile(const ConvParamsE& p, int tile, bool one_tap, hipSt
 
 void launch_conv_bf16(const ConvParamsE& p0, hipStream_t s) {
   ConvParamsE p = p0;
-  FE_CHECK(p.x && p.w && p.y && p.ldy >= p.Cout && p.ldx >= p.Cin, "conv_bf16: null operand or row stride below the channel count");
+  FE_CHECK(p.x && p.w && (p.y || p.y32) && (!p.y || p.ldy >= p.Cout) && p.ldx >= p.Cin, "conv_bf16: null operand or row stride below the channel count");
+  const bool f32s = p.y32 || p.res32;      // fp32 residual / output streams (FE_PRECISION_RES32 models)
+  FE_CHECK(!f32s || ((!p.y32 || p.ldy32 >= p.Cout) && (!p.res32 || p.ldr32 >= p.Cout) && !p.res && !p.pad_store && p.batch <= 1 && p.act != ACT_PRELU),
+           "conv_bf16: fp32 streams take no 2-byte residual / pad_store / batched launch / PReLU");
+  if (!p.y) p.ldy = 0;
   if (p.ldw == 0) p.ldw = p.Kp;
   if (p.batch < 1) p.batch = 1;
   if (p.nb1 < 1) p.nb1 = 1;
@@ -55,7 +60,8 @@ void launch_conv_bf16(const ConvParamsE& p0, hipStream_t s) {
   const unsigned long long xs = ((unsigned long long)p.N * p.H * p.W - 1) * (unsigned long long)p.ldx * 2 + (unsigned long long)p.Cin * 2;
   const unsigned long long ws = ((unsigned long long)p.Cout - 1) * (unsigned long long)p.ldw * 2 + (unsigned long long)p.Kp * 2;
   {      // tensors past 4 GiB (input, or the output / residual the wide tiles address through buffers): image groups that fit
-    const unsigned long long ysp = (unsigned long long)p.M * (unsigned long long)(p.ldy > p.ldr ? p.ldy : p.ldr) * 2;
+    unsigned long long ysp = (unsigned long long)p.M * (unsigned long long)(p.ldy > p.ldr ? p.ldy : p.ldr) * 2;
+    if (f32s) ysp = std::max(ysp, (unsigned long long)p.M * (unsigned long long)(p.ldy32 > p.ldr32 ? p.ldy32 : p.ldr32) * 4);
     if ((xs >= 0xFFFFFF00ull || ysp >= 0xFFFFFF00ull) && conv_split_by_images(p, [&](const ConvParamsE& sub) { launch_conv_bf16(sub, s); })) return;
   }
   FE_CHECK(xs < 0xFFFFFF00ull && ws < 0xFFFFFF00ull, "conv_bf16: operand spans exceed 32-bit buffer addressing");
@@ -65,6 +71,7 @@ void launch_conv_bf16(const ConvParamsE& p0, hipStream_t s) {
   auto al16 = [](const void* ptr) { return ((uintptr_t)ptr & 15) == 0; };
   const bool cout_ok = (p.Cout % 8 == 0) || (p.pad_store && ((p.Cout + 7) & ~7) <= p.ldy);
   p.vec_epi = cout_ok && (p.ldy % 8 == 0) && al16(p.y) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) &&
+              (!p.y32 || (p.ldy32 % 4 == 0 && al16(p.y32) && p.Cout % 8 == 0)) && (!p.res32 || (p.ldr32 % 4 == 0 && al16(p.res32) && p.Cout % 8 == 0)) &&
               (!p.gate || p.gate_c1 || (p.ldg % 8 == 0 && al16(p.gate))) && (!p.scale || al16(p.scale)) &&
               (!p.shift || (al16(p.shift) && p.hs1 % 4 == 0)) && (p.batch <= 1 || (p.ys1 % 8 == 0 && p.ys2 % 8 == 0));
   FE_CHECK(!p.pad_store || p.vec_epi, "conv_bf16: pad_store needs the vector epilogue");
@@ -113,8 +120,13 @@ void launch_conv_bf16(const ConvParamsE& p0, hipStream_t s) {
   const unsigned long long ysp = ((unsigned long long)(p.M - 1) * p.ldy + climit) * 2;
   const unsigned long long rsp = p.res ? ((unsigned long long)(p.M - 1) * p.ldr + p.Cout) * 2 : 0;
   const unsigned long long gsp = p.gate ? ((unsigned long long)(p.M - 1) * p.ldg + (p.gate_c1 ? 1 : p.Cout)) * 2 : 0;
-  const bool wide_ok = p.vec_epi && ysp < 0xFFFFFF00ull && rsp < 0xFFFFFF00ull && gsp < 0xFFFFFF00ull && (p.pad_store ? (!p.scale && !p.shift && !p.res && !p.gate) : true);
-  p.y_span = (unsigned)ysp; p.r_span = (unsigned)rsp; p.g_span = (unsigned)gsp;
+  const unsigned long long y32sp = p.y32 ? ((unsigned long long)(p.M - 1) * p.ldy32 + p.Cout) * 4 : 0;
+  const unsigned long long r32sp = p.res32 ? ((unsigned long long)(p.M - 1) * p.ldr32 + p.Cout) * 4 : 0;
+  // (a fp32 residual without an fp32 output has no wide form: h_epilogue_wide32 always writes p.y32)
+  const bool wide_ok = p.vec_epi && ysp < 0xFFFFFF00ull && rsp < 0xFFFFFF00ull && gsp < 0xFFFFFF00ull && (p.pad_store ? (!p.scale && !p.shift && !p.res && !p.gate) : true) &&
+                       y32sp < 0xFFFFFF00ull && r32sp < 0xFFFFFF00ull && (!f32s || (p.y32 && !p.gate));
+  p.y_span = p.y ? (unsigned)ysp : 0u; p.r_span = (unsigned)rsp; p.g_span = (unsigned)gsp;
+  p.y32_span = (unsigned)y32sp; p.r32_span = (unsigned)r32sp;
   if ((tile == 1 || tile == 8 || tile == 9) && !wide_ok) tile = 7;
   const bool one_tap = ntaps == 1 && p.Cin % 64 == 0 && p.Kp == p.Cin;
   if (p.cb == 16) launch_bf16_tile<2>(p, tile, false, s);

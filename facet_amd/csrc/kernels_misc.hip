@@ -706,6 +706,8 @@ template void launch_gemm_skinny<bf16, bf16, bf16>(const bf16*, int, const bf16*
 template void launch_gemm_skinny<bf16, bf16, float>(const bf16*, int, const bf16*, int, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 template void launch_gemm_skinny<f16, f16, f16>(const f16*, int, const f16*, int, const float*, const float*, f16*, int, int, int, int, int, hipStream_t);
 template void launch_gemm_skinny<f16, f16, float>(const f16*, int, const f16*, int, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+template void launch_gemm_skinny<float, bf16, float>(const float*, int, const bf16*, int, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+template void launch_gemm_skinny<float, f16, float>(const float*, int, const f16*, int, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 
 // RGB <-> BGR of a packed uint8 image batch (the reference keeps a PIL RGB and a cv2 BGR copy of every image,
 // processing/batch_processor.py:200-215; here the second one is made on the device from the resident first one).

@@ -163,16 +163,18 @@ __global__ void l2_normalize_kernel(const float* __restrict__ x, float* __restri
 }
 
 // x: [B,224,224,4] fp32 (CLIP-normalised, 4th channel zero) -> feat: device fp32 [B][out_dim] (un-normalised features).
-// T = activation type of the tower (float | bf16): the 3-channel patch embedding always runs on the fp32 kernel, the last
-// projection always emits fp32.
-template <class T>
+// T = type of the GEMM operands (float | bf16 | f16), RT = type of the token stream (T, or float: FE_PRECISION_RES32 - the residual
+// stream x and the input of every LayerNorm stay fp32, LayerNorm writes the 2-byte operand of the next GEMM, the two projections that
+// add to the stream read and write it in fp32). The 3-channel patch embedding always runs on the fp32 kernel, the last projection
+// always emits fp32.
+template <class T, class RT>
 void clip_forward(Ctx& c, const ClipModel& m, const Tensor& x, float* feat) {
   const size_t mark = c.arena.mark();
   const int B = x.n, d = m.width, Tk = m.tokens, P = m.patch_size;
   const int gh = x.h / P, gw = x.w / P;
   FE_CHECK(gh * gw + 1 == Tk, "clip: %dx%d input gives %d patches, positional_embedding has %d tokens", x.h, x.w, gh * gw, Tk);
-  T* tok = c.arena.array<T>((size_t)B * Tk * d);
-  float* patch = sizeof(T) == 4 ? reinterpret_cast<float*>(tok) : c.arena.array<float>((size_t)B * Tk * d);
+  RT* tok = c.arena.array<RT>((size_t)B * Tk * d);
+  float* patch = sizeof(RT) == 4 ? reinterpret_cast<float*>(tok) : c.arena.array<float>((size_t)B * Tk * d);
   {  // patch embed, one batch entry per image so rows land at patch[b][1 + p]
     ConvParams p{};
     p.x = x.p; p.ldx = x.ld; p.w = m.patch.w; p.y = patch + d; p.ldy = d;
@@ -183,21 +185,21 @@ void clip_forward(Ctx& c, const ClipModel& m, const Tensor& x, float* feat) {
     launch_conv(p, c.stream);
     c.flops_accum += 2.0 * B * p.M * (double)(P * P * m.patch.Cin) * d;
   }
-  hipLaunchKernelGGL(clip_embed_kernel<T>, dim3(2048), dim3(256), 0, c.stream, patch, tok, m.cls, m.pos, B, Tk, d);
+  hipLaunchKernelGGL(clip_embed_kernel<RT>, dim3(2048), dim3(256), 0, c.stream, patch, tok, m.cls, m.pos, B, Tk, d);
   FE_HIP(hipGetLastError());
   const int rows = B * Tk;
-  T* xa = c.arena.array<T>((size_t)rows * d);
+  RT* xa = c.arena.array<RT>((size_t)rows * d);
   T* nb = c.arena.array<T>((size_t)rows * d);
   T* hb = c.arena.array<T>((size_t)rows * 4 * d);
   launch_layernorm(tok, d, xa, d, m.ln_pre.g, m.ln_pre.b, rows, d, m.ln_pre.eps, c.stream);
-  T* cur = xa;
-  T* other = tok;
+  RT* cur = xa;
+  RT* other = tok;
   for (const ClipBlockW& w : m.blocks) {
     launch_layernorm(cur, d, nb, d, w.ln1.g, w.ln1.b, rows, d, w.ln1.eps, c.stream);
-    mha_forward<T>(c, w.attn, nb, d, nb, d, B, Tk, Tk, cur, d, other, d);          // other = cur + attn(ln1(cur))
+    mha_forward<T, RT>(c, w.attn, nb, d, nb, d, B, Tk, Tk, cur, d, other, d);          // other = cur + attn(ln1(cur))
     launch_layernorm(other, d, nb, d, w.ln2.g, w.ln2.b, rows, d, w.ln2.eps, c.stream);
     linear_forward(c, w.fc, nb, d, rows, hb, w.fc.Cout, ACT_GELU);
-    linear_forward(c, w.proj, hb, w.fc.Cout, rows, cur, d, ACT_NONE, other, d);  // cur = other + mlp(ln2(other))
+    linear_forward_res(c, w.proj, (const T*)hb, w.fc.Cout, rows, cur, d, ACT_NONE, (const RT*)other, d);  // cur = other + mlp(ln2(other))
   }
   // ln_post on the class token of every image (row stride Tk*d), then the projection (fp32 out)
   T* pooled = c.arena.array<T>((size_t)B * d);
@@ -205,9 +207,11 @@ void clip_forward(Ctx& c, const ClipModel& m, const Tensor& x, float* feat) {
   linear_forward_f32(c, m.proj, pooled, d, B, feat, m.out_dim, ACT_NONE);
   c.arena.rewind(mark);
 }
-template void clip_forward<float>(Ctx&, const ClipModel&, const Tensor&, float*);
-template void clip_forward<bf16>(Ctx&, const ClipModel&, const Tensor&, float*);
-template void clip_forward<f16>(Ctx&, const ClipModel&, const Tensor&, float*);
+template void clip_forward<float, float>(Ctx&, const ClipModel&, const Tensor&, float*);
+template void clip_forward<bf16, bf16>(Ctx&, const ClipModel&, const Tensor&, float*);
+template void clip_forward<f16, f16>(Ctx&, const ClipModel&, const Tensor&, float*);
+template void clip_forward<bf16, float>(Ctx&, const ClipModel&, const Tensor&, float*);
+template void clip_forward<f16, float>(Ctx&, const ClipModel&, const Tensor&, float*);
 
 // raw[b] = Linear(256,1)(relu(Linear(768,256)(feat[b])))   (reference scorer.py:579-583; (x+1)*5 clamp stays on host)
 void aesthetic_forward(Ctx& c, const AestheticModel& m, const float* feat, int B, float* raw) {

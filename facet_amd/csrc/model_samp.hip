@@ -5,6 +5,7 @@
 // conv epilogue. Parity: PINNED against the reference's own classes through tests/golden/samp_golden.npz.
 #include "engine.h"
 #include <cmath>
+#include <type_traits>
 
 namespace fe {
 
@@ -187,11 +188,12 @@ __device__ inline void region(const T* fm, int c, int r0, int r1, int c0, int c1
   mx = m; av = s / (float)((r1 - r0) * (c1 - c0));
 }
 
-template <class T>
-__global__ void samp_patterns_kernel(const T* __restrict__ fmap, const T* __restrict__ sal7, PatOut<T> o) {
+// TF: element type of the feature map, TS: of the saliency map, T: of the pattern vectors written
+template <class TF, class TS, class T>
+__global__ void samp_patterns_kernel(const TF* __restrict__ fmap, const TS* __restrict__ sal7, PatOut<T> o) {
   const int b = blockIdx.x, t = threadIdx.x;
-  const T* fm = fmap + (size_t)b * 49 * 512;
-  const T* sal = sal7 + (size_t)b * 49;
+  const TF* fm = fmap + (size_t)b * 49 * 512;
+  const TS* sal = sal7 + (size_t)b * 49;
   __shared__ float sal_small[16];
   if (t < 16) {  // adaptive_avg_pool2d(7x7 -> 4x4)
     const int i = t / 4, j = t % 4;
@@ -286,38 +288,53 @@ __global__ void samp_aggregate_kernel(const float* __restrict__ pw, const T* __r
   }
 }
 
-// x: fp32 [B,224,224,4], sal: [B,224,224,1] (type T); outputs are fp32 device pointers [B*8], [B*6], [B*5].
-// T = activation type of the trunk and the pattern module; the attribute / composition heads behind the pattern aggregation
-// (a 1024-vector per image) always run in fp32.
-template <class T>
-void sampnet_forward(Ctx& c, const SampModel& m, const Tensor& x, const TensorT<T>& sal, float* pw, float* attrs, float* dist) {
+// x: fp32 [B,224,224,4], sal: [B,224,224,1] (type TS); outputs are fp32 device pointers [B*8], [B*6], [B*5].
+// T = operand type of the trunk and the pattern module; the attribute / composition heads behind the pattern aggregation
+// (a 1024-vector per image) always run in fp32. Under FE_PRECISION_RES32 (2-byte T) the trunk keeps its skip stream in fp32 and the
+// pattern module reads the fp32 feature map, pools in fp32 and multiplies the fp32 vectors with the 2-byte weights (fp32 out): no
+// activation behind the trunk is rounded.
+template <class T, class TS>
+void sampnet_forward(Ctx& c, const SampModel& m, const Tensor& x, const TensorT<TS>& sal, float* pw, float* attrs, float* dist) {
   const size_t mark = c.arena.mark();
   const int B = x.n;
-  TensorT<T> fm = resnet_forward<T>(c, m.backbone, x, nullptr);
+  const bool r32 = sizeof(T) == 2 && m.dw.res32;
+  Tensor fm32;
+  TensorT<T> fm = resnet_forward<T>(c, m.backbone, x, nullptr, r32, &fm32);
   FE_CHECK(fm.h == 7 && fm.w == 7 && fm.c == 512 && fm.ld == 512, "SAMP-Net expects a 7x7x512 feature map (224x224 input), got %dx%dx%d", fm.h, fm.w, fm.c);
   // saliency: two 3x3/s2/p1 max pools (samp_net.py:692-695), then bilinear to 7x7 (:613-618)
-  TensorT<T> s1 = c.arena.tensor_t<T>(B, conv_out_dim(sal.h, 3, 2, 1, 1), conv_out_dim(sal.w, 3, 2, 1, 1), 1);
+  TensorT<TS> s1 = c.arena.tensor_t<TS>(B, conv_out_dim(sal.h, 3, 2, 1, 1), conv_out_dim(sal.w, 3, 2, 1, 1), 1);
   launch_maxpool(sal, s1, 3, 2, 1, c.stream);
-  TensorT<T> s2 = c.arena.tensor_t<T>(B, conv_out_dim(s1.h, 3, 2, 1, 1), conv_out_dim(s1.w, 3, 2, 1, 1), 1);
+  TensorT<TS> s2 = c.arena.tensor_t<TS>(B, conv_out_dim(s1.h, 3, 2, 1, 1), conv_out_dim(s1.w, 3, 2, 1, 1), 1);
   launch_maxpool(s1, s2, 3, 2, 1, c.stream);
-  TensorT<T> s7 = c.arena.tensor_t<T>(B, 7, 7, 1);
+  TensorT<TS> s7 = c.arena.tensor_t<TS>(B, 7, 7, 1);
   launch_bilinear(s2, s7, c.stream);
-  PatOut<T> po;
-  for (int i = 0; i < 8; ++i) {
-    po.ld[i] = sizeof(T) == 2 ? m.pattern[i].KpH : m.pattern[i].Kp;   // zero padded up to the packed K of the pattern "convs"
-    po.f[i] = c.arena.array<T>((size_t)B * po.ld[i]);
-    FE_HIP(hipMemsetAsync(po.f[i], 0, (size_t)B * po.ld[i] * sizeof(T), c.stream));
-  }
-  po.relu_gavg = c.arena.array<float>((size_t)B * 512);
-  hipLaunchKernelGGL(samp_patterns_kernel<T>, dim3(B), dim3(256), 0, c.stream, fm.p, s7.p, po);
-  FE_HIP(hipGetLastError());
-  linear_forward(c, m.pattern_weight, (const float*)po.relu_gavg, 512, B, pw, 8, ACT_NONE);
-  T* patt = c.arena.array<T>((size_t)8 * B * 1024);
-  for (int i = 0; i < 8; ++i)
-    linear_forward(c, m.pattern[i], (const T*)po.f[i], po.ld[i], B, patt + (size_t)i * B * 1024, 1024, ACT_NONE);
+  float* relu_gavg = c.arena.array<float>((size_t)B * 512);
   float* agg = c.arena.array<float>((size_t)B * 1024);
-  hipLaunchKernelGGL(samp_aggregate_kernel<T>, dim3(B), dim3(256), 0, c.stream, pw, patt, agg, B);
-  FE_HIP(hipGetLastError());
+  auto pattern_stage = [&](auto* ftag, auto* ptag) {
+    typedef std::remove_pointer_t<decltype(ftag)> TF;      // feature-map element
+    typedef std::remove_pointer_t<decltype(ptag)> TP;      // pattern-vector element
+    PatOut<TP> po;
+    for (int i = 0; i < 8; ++i) {
+      po.ld[i] = sizeof(T) == 2 ? m.pattern[i].KpH : m.pattern[i].Kp;   // zero padded up to the packed K of the pattern "convs"
+      po.f[i] = c.arena.array<TP>((size_t)B * po.ld[i]);
+      FE_HIP(hipMemsetAsync(po.f[i], 0, (size_t)B * po.ld[i] * sizeof(TP), c.stream));
+    }
+    po.relu_gavg = relu_gavg;
+    const TF* fmp;
+    if constexpr (sizeof(TF) == sizeof(T)) fmp = reinterpret_cast<const TF*>(fm.p); else fmp = reinterpret_cast<const TF*>(fm32.p);
+    hipLaunchKernelGGL((samp_patterns_kernel<TF, TS, TP>), dim3(B), dim3(256), 0, c.stream, fmp, (const TS*)s7.p, po);
+    FE_HIP(hipGetLastError());
+    linear_forward(c, m.pattern_weight, (const float*)relu_gavg, 512, B, pw, 8, ACT_NONE);
+    TP* patt = c.arena.array<TP>((size_t)8 * B * 1024);
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (sizeof(TP) == 4 && sizeof(T) == 2) linear_forward_xf32(c, m.pattern[i], m.dw.prec, (const float*)po.f[i], po.ld[i], B, (float*)(patt + (size_t)i * B * 1024), 1024, ACT_NONE);
+      else linear_forward(c, m.pattern[i], (const T*)po.f[i], po.ld[i], B, (T*)(patt + (size_t)i * B * 1024), 1024, ACT_NONE);
+    }
+    hipLaunchKernelGGL(samp_aggregate_kernel<TP>, dim3(B), dim3(256), 0, c.stream, pw, (const TP*)patt, agg, B);
+    FE_HIP(hipGetLastError());
+  };
+  if (r32) pattern_stage((float*)nullptr, (float*)nullptr);
+  else pattern_stage((T*)nullptr, (T*)nullptr);
   float* h1 = c.arena.array<float>((size_t)B * 1024);
   float* h2 = c.arena.array<float>((size_t)B * 512);
   linear_forward(c, m.att_feat, (const float*)agg, 1024, B, h2, 512, ACT_RELU);
@@ -328,8 +345,10 @@ void sampnet_forward(Ctx& c, const SampModel& m, const Tensor& x, const TensorT<
   launch_softmax_rows(dist, 5, B, 5, c.stream);
   c.arena.rewind(mark);
 }
-template void sampnet_forward<float>(Ctx&, const SampModel&, const Tensor&, const Tensor&, float*, float*, float*);
-template void sampnet_forward<bf16>(Ctx&, const SampModel&, const Tensor&, const TensorH&, float*, float*, float*);
-template void sampnet_forward<f16>(Ctx&, const SampModel&, const Tensor&, const TensorF16&, float*, float*, float*);
+#define FE_SAMP_INST(T, TS) template void sampnet_forward<T, TS>(Ctx&, const SampModel&, const Tensor&, const TensorT<TS>&, float*, float*, float*);
+FE_SAMP_INST(float, float) FE_SAMP_INST(float, bf16) FE_SAMP_INST(float, f16)
+FE_SAMP_INST(bf16, float) FE_SAMP_INST(bf16, bf16) FE_SAMP_INST(bf16, f16)
+FE_SAMP_INST(f16, float) FE_SAMP_INST(f16, bf16) FE_SAMP_INST(f16, f16)
+#undef FE_SAMP_INST
 
 }  // namespace fe

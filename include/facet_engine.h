@@ -92,6 +92,8 @@ int fe_flops_get(fe_ctx* ctx, double* flops);
 /* Same counter minus the multiply-adds saved where a layer ran as Winograd F(2x2,3x3) (16 instead of 36 per 2x2 outputs):
  * the FLOPs the matrix cores actually executed. fe_flops_get stays the algorithmic (direct-convolution) count. */
 int fe_flops_get_executed(fe_ctx* ctx, double* flops);
+/* the part of fe_flops_get issued on the 2-byte (bf16 / fp16) matrix instructions: lets a mixed-precision run be priced per dtype */
+int fe_flops_get_half(fe_ctx* ctx, double* flops);
 
 /* ---- weights: replaces state_dict loading inside pyiqa.create_metric / open_clip.create_model /
  *      SAMPNet.load_state_dict (models/pyiqa_scorer.py:108, model_manager.py:140, samp_net.py:895).

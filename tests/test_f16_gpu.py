@@ -75,3 +75,33 @@ def test_f16_stores_saturate_instead_of_overflowing(engf16):
         got = engf16.conv2d(x, w)
         assert np.isfinite(got).all()
         assert (got[:, 0::2] == 65504.0).all() and (got[:, 1::2] == -65504.0).all()
+
+
+@pytest.mark.parametrize("prec", ["f16+r32", "bf16+r32"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_fp32_stream_forms_of_the_2byte_kernel(case, prec):
+    """FE_PRECISION_RES32: 2-byte GEMM operands, the residual read as fp32 and the result written as fp32 rows (and as 2-byte rows,
+    which fe_op_conv2d checks to be the rounding of the fp32 ones). Against torch's fp32 convolution of the rounded operands with the
+    UNROUNDED fp32 residual; the result is not rounded, so the tolerance is fp32 summation order (+ the tanh GELU form)."""
+    from facet_amd import Engine
+    n, cin, h, w, cout, k, stride, pad, dil, act, with_res = case
+    rnd = (lambda a: torch.from_numpy(np.asarray(a, np.float32)).half().float()) if prec.startswith("f16") else \
+          (lambda a: torch.from_numpy(np.asarray(a, np.float32)).bfloat16().float())
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    x = rnd(rng.normal(0, 1, (n, cin, h, w)))
+    wt = rnd(rng.normal(0, 1.0 / np.sqrt(cin * k * k), (cout, cin, k, k)))
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.2, cout).astype(np.float32)
+    ref = F.conv2d(x, wt, stride=stride, padding=pad, dilation=dil) * torch.from_numpy(scale).view(1, -1, 1, 1) + torch.from_numpy(shift).view(1, -1, 1, 1)
+    res = None
+    if with_res:
+        res = torch.from_numpy(rng.normal(0, 1, tuple(ref.shape)).astype(np.float32))      # fp32, not rounded
+        ref = ref + res
+    ref = {None: lambda t: t, "relu": F.relu, "gelu": F.gelu, "sigmoid": torch.sigmoid, "softplus": F.softplus}[act](ref).numpy()
+    e = Engine(0, arena_bytes=2 << 30, precision=prec)
+    try:
+        got = e.conv2d(x.numpy(), wt.numpy(), scale=scale, shift=shift, res=None if res is None else res.numpy(), stride=stride, pad=pad, dil=dil, act=act)
+    finally:
+        e.close()
+    tol = (6e-4 if act == "gelu" else 2e-5) * np.abs(ref).max()
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= tol, f"worst {np.abs(got - ref).max():.3e} (max|ref| {np.abs(ref).max():.3e})"
