@@ -95,7 +95,17 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
     imgs = synthetic_images(2, sample, hw, hw)
     # the whole host, whatever share of it the launcher gave this rank's OpenMP pool (self_launch sets OMP_NUM_THREADS = cpus / N
     # for the ranks' own host glue): the baseline at N > 1 is the same measurement as at N = 1
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    try:
+        import psutil
+        host_threads = psutil.cpu_count(logical=False) or os.cpu_count() or 1      # physical cores: torch's own default at N = 1
+    except ImportError:
+        host_threads = os.cpu_count() or 1
+    try:
+        host_threads = min(host_threads, len(os.sched_getaffinity(0)))             # never more than this process may run on
+    except AttributeError:
+        pass
+    if torch.get_num_threads() != host_threads:      # (only a launcher-limited rank changes its pool: at N = 1 this is torch's default)
+        torch.set_num_threads(max(1, host_threads))
     cores = torch.get_num_threads()
     extras = []
     if workload in ("faces", "full"):
@@ -276,16 +286,24 @@ def main():
     def mb_of(policy, mask=7):
         return args.microbatch * 2 if half_share(policy, mask) else args.microbatch
 
+    sd_cache = {}
+
+    def sd_of(name):      # the seeded checkpoints are drawn once per process, whatever number of contexts loads them
+        if name not in sd_cache:
+            sd_cache[name] = synthetic_state_dict(name, seed=3)
+        return sd_cache[name]
+
+    t_start = time.time()
+
+    def progress(msg):      # stderr: the one JSON line stays alone on stdout; a run that prints nothing for minutes looks hung
+        if rank == 0:
+            print(f"[bench +{time.time() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
     def make_engine(policy, mask):
         e = Engine(dev_index, arena_bytes=(4 + 2 * args.microbatch * max(1, (HW * HW) // (1024 * 1024))) << 30)
-        sds = {"topiq": synthetic_state_dict("topiq", seed=3)}
-        if mask & 2:
-            sds["clip"] = synthetic_state_dict("clip", seed=3)
-            sds["aesthetic"] = synthetic_state_dict("aesthetic", seed=3)
-        if mask & 4:
-            sds["u2netp"] = synthetic_state_dict("u2netp", seed=3)
-            sds["samp_net"] = synthetic_state_dict("samp_net", seed=3)
-        precision_mod.load_models(e, policy, sds)      # precision is a property of a model's committed weights
+        names = ["topiq"] + (["clip", "aesthetic"] if mask & 2 else []) + (["u2netp", "samp_net"] if mask & 4 else [])
+        precision_mod.load_models(e, policy, {n: sd_of(n) for n in names})      # precision is a property of a model's committed weights
+        progress(f"context ready: {precision_mod.describe(policy)}")
         # 2-byte activations are half the bytes: the same arena holds twice the images per micro-batch (fewer, larger launches)
         e.set_microbatch(mb_of(policy, mask))
         return e
@@ -419,6 +437,7 @@ def main():
         return r
 
     dt_max, ev_ms, flops, flops_exec, flops_half = measure(primary, args.steps, args.warmup, eng)
+    progress(f"{primary} [{args.dtype}]: {B * world * args.steps / dt_max:.1f} images/s")
     overrides = {k: v for k, v in os.environ.items() if k.startswith("FE_") or k == "FACET_AMD_LIB"}      # tuning hooks that change the measured path
     out = None
     if rank == 0:
@@ -441,31 +460,39 @@ def main():
     sub = {}
     sub_runs = [(wl, wl, args.dtype, 10 if wl == "topiq_clip" else 3) for wl in subs]
     if not (args.no_sub or world > 1) and args.dtype == "f32":
-        sub_runs += [("ensemble_parity", "ensemble", "parity", 3),        # configs[3] under the policy that holds the 1e-3 gate
-                     ("ensemble_fast16", "ensemble", "fast16", 3),        # every model in fp16 (fp32 residual streams)
-                     ("ensemble_bf16", "ensemble", "bf16", 3)]            # BASELINE configs[3] taken literally
-        if primary == "full":
-            sub_runs += [("full_clip_f16", "full", "reference_gpu", 3),   # the reference's own GPU precisions: CLIP halved, the rest fp32
-                         ("full_parity", "full", "parity", 3)]            # the metric's workload under the parity-holding policy
+        full = primary == "full"
+        sub_runs += [("ensemble_parity", "ensemble", "parity", 3)]            # configs[3] under the policy that holds the 1e-3 gate
+        if full:
+            sub_runs += [("full_parity", "full", "parity", 3),                # the metric's workload under that policy
+                         ("full_clip_f16", "full", "reference_gpu", 3)]       # the reference's own GPU precisions: CLIP halved, the rest fp32
+        sub_runs += [("ensemble_fast16", "ensemble", "fast16", 3),            # every model in fp16 (fp32 residual streams)
+                     ("ensemble_bf16", "ensemble", "bf16", 3)]                # BASELINE configs[3] taken literally
+    spare, spare_pol = None, None      # one spare context at a time, shared by consecutive runs of one policy
     for key, wl, pol, s_steps in sub_runs:
         s_warm = 1
-        spare = None
         e = eng
         if pol != args.dtype:
-            e = spare = make_engine(pol, WL[wl][0])
+            if spare_pol != pol:
+                if spare is not None:
+                    spare.close()
+                spare, spare_pol = make_engine(pol, 7), pol
+            e = spare
         dts, evs, fl, fx, fh = measure(wl, s_steps, s_warm, e)
+        progress(f"sub.{key}: {B * s_steps / dts:.1f} images/s")
         sub[key] = {"value": round(B * s_steps / dts, 2), "unit": "images/s", "steps": s_steps, "warmup": s_warm,
                     "ms_per_step": round(dts / s_steps * 1e3, 3), "dtype": DTYPE_FIELD[pol],
                     "config": {"workload": workload_text(wl, B, HW, pol), "precision": precision_mod.describe(pol),
                                "microbatch": mb_of(pol, WL[wl][0])},
                     "roofline": roofline(wl, s_steps, evs, fl, fx, fh, e, pol)}
-        if spare is not None:
-            spare.close()
+    if spare is not None:
+        spare.close()
     if rank == 0:
         if sub:
             out["sub"] = sub
         if args.cpu_sample > 0:
+            progress("cpu_baseline ...")
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, HW, 3, primary)
+            progress(f"cpu_baseline: {out['cpu_baseline']['value']} images/s on {out['cpu_baseline']['cores']} threads")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -187,20 +187,17 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
       const unsigned co = c0 < p.Cout ? (unsigned)c0 * 4u : OOB;
       const h_v4 sc = __builtin_bit_cast(h_v4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)co, 0, 0));
       const h_v4 sf = __builtin_bit_cast(h_v4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)co, 0, 0));
-      h_v4 rv[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        rv[i] = __builtin_bit_cast(h_v4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)((rok[i] && c0 < p.Cout) ? rbo[i] + (unsigned)c0 * 4u : OOB), 0, 0));
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         float v[4];
+        const h_v4 rvi = __builtin_bit_cast(h_v4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)((rok[i] && c0 < p.Cout) ? rbo[i] + (unsigned)c0 * 4u : OOB), 0, 0));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = acc[i][j][4 * g + e] * (hs ? sc[e] : 1.f) + sf[e];
-          if (!p.res_after_act) x += rv[i][e];
+          if (!p.res_after_act) x += rvi[e];
           if (ACTK == 1) x = x > 0.f ? x : 0.f;
           else if (ACTK < 0) x = fe_apply_act_fast(x, p.act);
-          if (p.res_after_act) x += rv[i][e];
+          if (p.res_after_act) x += rvi[e];
           v[e] = x;
           acc[i][j][4 * g + e] = x;          // kept for the fp32 pass below
         }
@@ -210,6 +207,9 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
           *reinterpret_cast<h_v2u*>(stage + (32 * i + r) * PITCH + (32 * j + 8 * g + 4 * h) * 2) = o;
         }
       }
+      // one (column block, quad) group at a time: hoisting the residual quads of all eight groups (4 VGPRs x TM each) beside the
+      // accumulators spilled the 256-row tiles
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (OUT == 2) {
@@ -221,6 +221,7 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
       const int row = it * RPI + lr, m = row0 + row;
       const h_v4 d = *reinterpret_cast<const h_v4*>(stage + row * PITCH + lc * 16);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h_v4u, d), ry, (int)((m < p.M && c < p.Cout) ? (unsigned)m * (unsigned)(p.ldy * 2) + (unsigned)c * 2u : OOB), 0, 0);
+      if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
   // fp32 rows: one 32-column block of the wave tile at a time through the same staging region
@@ -243,13 +244,16 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
       const int row = it * 8 + lr, m = row0 + row;
       const h_v4 d = *reinterpret_cast<const h_v4*>(stage + row * PITCH + lc * 16);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h_v4u, d), ry32, (int)((m < p.M && c < p.Cout) ? (unsigned)m * (unsigned)(p.ldy32 * 4) + (unsigned)c * 4u : OOB), 0, 0);
+      if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows in flight at a time (the accumulators of the other column block are still live)
     }
   }
 }
 
 // UNITS = 32 / cb: (channel block, tap) units per 32-element slab. MODE 0 plain, 2 PReLU epilogue.
 // ONE_TAP: 1x1 kernels (GEMMs) - no tap masks, the K offset of a slab goes into the scalar offset of the buffer load.
-template <class E, int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
+// S32: the fp32-stream form of the layer (p.res32 / p.y32, FE_PRECISION_RES32 models) - its own instantiations, so the plain kernels
+// keep their register budgets (with the fp32 residual quads inlined beside the eleven plain forms the 256-row tiles spilled).
+template <class E, int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false, bool S32 = false>
 __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM * 32 % 64 == 0 && WGN * TN * 32 % 64 == 0 ? 3 : 2) : 3)))) void conv_bf16_kernel(ConvParamsT<E> p, const int ntiles, const int ntotal) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int NW = WGM * WGN;                              // waves per workgroup: 4, or 8 for the 256x256 tile
@@ -383,11 +387,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
       // straight-line forms of the combinations the models use; the rest (softplus gates, residual after the activation) take the
       // form that reads activation, gate and residual order from the parameters
       const bool plain = !p.gate && !(p.res && p.res_after_act);
-      if (p.y32) {      // fp32-stream forms (launch_conv_bf16 admits them only without gate / E-typed residual / pad_store)
+      if constexpr (S32) {      // fp32-stream forms (launch_conv_bf16 admits them only without gate / E-typed residual / pad_store)
         if (!p.y && p.act == ACT_NONE && !p.res_after_act) h_epilogue_wide32<E, TM, TN, 0, 1>(acc, p, row0, col0, lane, stage);        // ViT projections
         else if (p.y && p.act == ACT_RELU && !p.res_after_act) h_epilogue_wide32<E, TM, TN, 1, 2>(acc, p, row0, col0, lane, stage);    // ResNet block outputs
         else h_epilogue_wide32<E, TM, TN, -1, 2>(acc, p, row0, col0, lane, stage);      // anything else (a null p.y is an empty buffer: stores dropped)
-      } else if (plain && p.act == ACT_NONE) {
+        return;
+      }
+      if (plain && p.act == ACT_NONE) {
         if (p.res) h_epilogue_wide<E, TM, TN, 0, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<E, TM, TN, 0, false, false>(acc, p, row0, col0, lane, stage);
       } else if (plain && p.act == ACT_RELU) {
         if (p.res) h_epilogue_wide<E, TM, TN, 1, true, false>(acc, p, row0, col0, lane, stage); else h_epilogue_wide<E, TM, TN, 1, false, false>(acc, p, row0, col0, lane, stage);
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           for (int e = 0; e < 16; ++e) Et[((e & 3) + 8 * (e >> 2) + 4 * h) * ES + j * 32 + r] = acc[i][j][e];
         const int mrow0 = m0 + wm * TM * 32 + i * 32 + lr;
         uint4 rv[NIT];
-        float4 r32a[NIT], r32b[NIT];      // fp32 residual rows (FE_PRECISION_RES32 streams)
+        float4 r32a[S32 ? NIT : 1], r32b[S32 ? NIT : 1];      // fp32 residual rows (FE_PRECISION_RES32 streams)
         float gs[NIT];
         uint4 gv[NIT];
   #pragma unroll
@@ -625,9 +631,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           const int mc = m < p.M ? m : p.M - 1;
           if constexpr (RES_AHEAD) { if (p.res) rv[it] = rall[i * NIT + it]; }
           else if (p.res) rv[it] = *reinterpret_cast<const uint4*>(p.res + (size_t)mc * p.ldr + colc);
-          if (p.res32) {
-            r32a[it] = *reinterpret_cast<const float4*>(p.res32 + (size_t)mc * p.ldr32 + colc);
-            r32b[it] = *reinterpret_cast<const float4*>(p.res32 + (size_t)mc * p.ldr32 + colc + 4);
+          if constexpr (S32) {
+            if (p.res32) {
+              r32a[it] = *reinterpret_cast<const float4*>(p.res32 + (size_t)mc * p.ldr32 + colc);
+              r32b[it] = *reinterpret_cast<const float4*>(p.res32 + (size_t)mc * p.ldr32 + colc + 4);
+            }
           }
           if (p.gate) {
             if (p.gate_c1) gs[it] = (float)p.gate[(size_t)mc * p.ldg];
@@ -641,11 +649,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           const float4 v1 = *reinterpret_cast<const float4*>(&Et[(lr + it * RPI) * ES + lc + 4]);
           float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
           float rf[8], gf[8];
-          const bool hres = p.res || p.res32;
+          bool hres = p.res != nullptr;
           if (p.res) h_unpack8<E>(rv[it], rf);
-          else if (p.res32) {
-            rf[0] = r32a[it].x; rf[1] = r32a[it].y; rf[2] = r32a[it].z; rf[3] = r32a[it].w;
-            rf[4] = r32b[it].x; rf[5] = r32b[it].y; rf[6] = r32b[it].z; rf[7] = r32b[it].w;
+          if constexpr (S32) {
+            if (p.res32) {
+              hres = true;
+              rf[0] = r32a[it].x; rf[1] = r32a[it].y; rf[2] = r32a[it].z; rf[3] = r32a[it].w;
+              rf[4] = r32b[it].x; rf[5] = r32b[it].y; rf[6] = r32b[it].z; rf[7] = r32b[it].w;
+            }
           }
           if (p.gate && !p.gate_c1) h_unpack8<E>(gv[it], gf);
   #pragma unroll
@@ -663,10 +674,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           o.u = make_uint4(fe_pack2((const E*)nullptr, v[0], v[1]), fe_pack2((const E*)nullptr, v[2], v[3]),
                            fe_pack2((const E*)nullptr, v[4], v[5]), fe_pack2((const E*)nullptr, v[6], v[7]));
           if (cok && m < p.M) {
-            if (p.y) *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + colb) = o.u;
-            if (p.y32) {      // (vec_epi with an fp32 output: Cout % 8 == 0, no pad_store)
-              *reinterpret_cast<float4*>(p.y32 + (size_t)m * p.ldy32 + colb) = make_float4(v[0], v[1], v[2], v[3]);
-              *reinterpret_cast<float4*>(p.y32 + (size_t)m * p.ldy32 + colb + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            if constexpr (S32) {
+              if (p.y) *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + colb) = o.u;
+              if (p.y32) {      // (vec_epi with an fp32 output: Cout % 8 == 0, no pad_store)
+                *reinterpret_cast<float4*>(p.y32 + (size_t)m * p.ldy32 + colb) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(p.y32 + (size_t)m * p.ldy32 + colb + 4) = make_float4(v[4], v[5], v[6], v[7]);
+              }
+            } else {
+              *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + colb) = o.u;
             }
           }
         }
@@ -688,14 +703,19 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           const int m = m0 + row;
           if (cok && m < p.M) {
             float v = acc[i][j][e] * sc + sf;
-            const float rs_ = p.res ? (float)p.res[(size_t)m * p.ldr + col] : (p.res32 ? p.res32[(size_t)m * p.ldr32 + col] : 0.f);
+            float rs_ = p.res ? (float)p.res[(size_t)m * p.ldr + col] : 0.f;
+            if constexpr (S32) { if (p.res32) rs_ = p.res32[(size_t)m * p.ldr32 + col]; }
             if (!p.res_after_act) v += rs_;
             if constexpr (MODE == 2) v = v > 0.f ? v : v * p.slope[col];
             else v = fe_apply_act(v, p.act);
             if (p.res_after_act) v += rs_;
             if (p.gate) v *= (float)p.gate[(size_t)m * p.ldg + (p.gate_c1 ? 0 : col)];
-            if (p.y) stf(&p.y[(size_t)m * p.ldy + col], v);
-            if (p.y32) p.y32[(size_t)m * p.ldy32 + col] = v;
+            if constexpr (S32) {
+              if (p.y) stf(&p.y[(size_t)m * p.ldy + col], v);
+              if (p.y32) p.y32[(size_t)m * p.ldy32 + col] = v;
+            } else {
+              stf(&p.y[(size_t)m * p.ldy + col], v);
+            }
           }
         }
       }
@@ -705,7 +725,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
   }
 }
 
-template <class E, int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false>
+template <class E, int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false, bool S32 = false>
 void launch_bf16_variant(const ConvParamsT<E>& p, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
@@ -713,7 +733,7 @@ void launch_bf16_variant(const ConvParamsT<E>& p, hipStream_t s) {
   constexpr size_t epi_lds = TN > 1 ? (size_t)(WGM * WGN) * (TM * 32) * (TN * 64 + 16)      // wide tiles: bf16 image of every wave's tile
                                     : (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
-  auto kern = conv_bf16_kernel<E, WGM, WGN, TM, TN, UNITS, MODE, ONE_TAP>;
+  auto kern = conv_bf16_kernel<E, WGM, WGN, TM, TN, UNITS, MODE, ONE_TAP, S32>;
   static std::atomic<uint64_t> lds_set{0};
   ensure_dynamic_lds((const void*)kern, lds, lds_set);
   const int ntotal = mtiles * ntiles;
@@ -734,5 +754,11 @@ void launch_bf16_variant(const ConvParamsT<E>& p, hipStream_t s) {
   X template void launch_bf16_variant<E, 2, 4, 4, 2, 1, 0, true>(const ConvParamsT<E>&, hipStream_t);      /* 256x256, eight waves */
 FE_WIDE_TILES(extern, bf16)
 FE_WIDE_TILES(extern, f16)
+// the fp32-stream forms of the wide tiles: kernels_conv_{bf16,f16}_s32.hip
+#define FE_WIDE_TILES_S32(X, E)                                                                                  \
+  X template void launch_bf16_variant<E, 2, 2, 2, 2, 1, 0, true, true>(const ConvParamsT<E>&, hipStream_t);  \
+  X template void launch_bf16_variant<E, 2, 2, 2, 2, 1, 0, false, true>(const ConvParamsT<E>&, hipStream_t);
+FE_WIDE_TILES_S32(extern, bf16)
+FE_WIDE_TILES_S32(extern, f16)
 
 }  // namespace fe

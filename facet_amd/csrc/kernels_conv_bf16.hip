@@ -10,6 +10,30 @@ namespace fe {
 
 typedef ConvParamsT<FE_E> ConvParamsE;
 
+// The fp32-stream forms (p.res32 / p.y32): their own instantiations of a reduced tile set (no 16-channel-block units, no slim tiles:
+// the layers that carry an fp32 stream are the ResNet block outputs / downsample branches and the ViT projections).
+static void launch_bf16_tile_s32(const ConvParamsE& p, int tile, bool one_tap, hipStream_t s) {
+  // reduced tile set: 128x128 for every wide choice (with the fp32 residual / output quads beside 128 accumulator registers the
+  // 256-row wave tiles spill), 128x64 / 64x64 narrow; no slim tiles, no 16-channel-block units
+  if (tile == 8 || tile == 9) tile = 1;
+  if (tile == 3) tile = 7;
+  if (tile == 5) tile = 4;
+  if (one_tap) {
+    switch (tile) {
+      case 1: launch_bf16_variant<FE_E, 2, 2, 2, 2, 1, 0, true, true>(p, s); return;
+      case 7: launch_bf16_variant<FE_E, 2, 2, 2, 1, 1, 0, true, true>(p, s); return;
+      case 4: launch_bf16_variant<FE_E, 2, 2, 1, 1, 1, 0, true, true>(p, s); return;
+      default: break;
+    }
+  }
+  switch (tile) {
+    case 1: launch_bf16_variant<FE_E, 2, 2, 2, 2, 1, 0, false, true>(p, s); break;
+    case 7: launch_bf16_variant<FE_E, 2, 2, 2, 1, 1, 0, false, true>(p, s); break;
+    case 4: launch_bf16_variant<FE_E, 2, 2, 1, 1, 1, 0, false, true>(p, s); break;
+    default: FE_CHECK(false, "conv_bf16: unknown tile %d", tile);
+  }
+}
+
 template <int UNITS>
 static void launch_bf16_tile(const ConvParamsE& p, int tile, bool one_tap, hipStream_t s) {
   FE_CHECK(p.act != ACT_PRELU, "conv_bf16: PReLU epilogue is not instantiated (no bf16 model uses it)");
@@ -129,7 +153,10 @@ void launch_conv_bf16(const ConvParamsE& p0, hipStream_t s) {
   p.y32_span = (unsigned)y32sp; p.r32_span = (unsigned)r32sp;
   if ((tile == 1 || tile == 8 || tile == 9) && !wide_ok) tile = 7;
   const bool one_tap = ntaps == 1 && p.Cin % 64 == 0 && p.Kp == p.Cin;
-  if (p.cb == 16) launch_bf16_tile<2>(p, tile, false, s);
+  if (f32s) {
+    FE_CHECK(p.cb == 32, "conv_bf16: fp32 streams are instantiated for 32-channel blocks only (Cin %% 32 == 0)");
+    launch_bf16_tile_s32(p, tile, one_tap, s);
+  } else if (p.cb == 16) launch_bf16_tile<2>(p, tile, false, s);
   else launch_bf16_tile<1>(p, tile, one_tap, s);
 }
 

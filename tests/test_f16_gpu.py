@@ -85,6 +85,8 @@ def test_fp32_stream_forms_of_the_2byte_kernel(case, prec):
     UNROUNDED fp32 residual; the result is not rounded, so the tolerance is fp32 summation order (+ the tanh GELU form)."""
     from facet_amd import Engine
     n, cin, h, w, cout, k, stride, pad, dil, act, with_res = case
+    if k > 1 and cin % 32:
+        pytest.skip("the fp32-stream forms are instantiated for 32-channel blocks (ResNet / ViT layers); 16-channel-block layers fail loudly")
     rnd = (lambda a: torch.from_numpy(np.asarray(a, np.float32)).half().float()) if prec.startswith("f16") else \
           (lambda a: torch.from_numpy(np.asarray(a, np.float32)).bfloat16().float())
     rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
