@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FACET_AMD_LIB") or os.path.join(_HERE, "libfacet_engine.so")   # env: developer A/B builds only
 
-FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_SAMP, FE_MODEL_U2NETP, FE_MODEL_AESTHETIC = range(5)
+FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_SAMP, FE_MODEL_U2NETP, FE_MODEL_AESTHETIC, FE_MODEL_VLM = range(6)
 FE_MODEL_SCRFD, FE_MODEL_ARCFACE = 5, 6
 FE_RECORD_FLOATS = 789
 FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC = 0, 1, 2
@@ -95,6 +95,10 @@ SIGNATURES = {
                                        _f32p, _f32p]),
     "fe_clip_encode_text": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int, _f32p]),
     "fe_tag_similarities": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, C.c_int, _f32p]),
+    "fe_vlm_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int)]),
+    "fe_vlm_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "fe_vlm_prefill": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), _f32p]),
+    "fe_vlm_decode_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), _f32p]),
     "fe_ensemble_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
                                     C.POINTER(C.c_int)]),
     "fe_u2netp_saliency": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
@@ -521,6 +525,80 @@ class Engine:
                                                                                      else d_records.value),
                                                 int(ld_records), C.byref(mask)))
         return mask.value
+
+    # -- VLM tagger text decoder (models/vlm_tagger.py) ---------------------------------------------------
+    def vlm_configure(self, n_heads=28, n_kv_heads=4, head_dim=128, rope_theta=1e6, rms_eps=1e-6, mrope_section=(16, 24, 24)):
+        """Geometry read by the NEXT load_weights(FE_MODEL_VLM, ...) (transformers Qwen2_5_VLTextConfig; defaults = Qwen2.5-VL-7B)."""
+        ms = (C.c_int * 3)(*[int(v) for v in mrope_section])
+        self._ck(self.lib.fe_vlm_configure(self.h, int(n_heads), int(n_kv_heads), int(head_dim), float(rope_theta), float(rms_eps), ms))
+
+    def vlm_dims(self):
+        d = (C.c_int * 8)()
+        self._ck(self.lib.fe_vlm_dims(self.h, d))
+        return dict(zip(("vocab", "hidden", "layers", "heads", "kv_heads", "intermediate", "max_seq", "cur_len"), list(d)))
+
+    @staticmethod
+    def _i32(a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+    def vlm_prefill(self, tokens, position_ids=None, max_seq=None, want_logits=False):
+        """tokens int [n_seq, len]; position_ids int [3, n_seq, len] (None: text-only positions 0..len-1 on all three axes).
+        -> next token ids [n_seq] (greedy) and, with want_logits, the bf16 logits widened to float32 [n_seq, vocab]."""
+        tok, tp = self._i32(tokens)
+        n, L = tok.shape
+        if position_ids is None:
+            position_ids = np.broadcast_to(np.arange(L, dtype=np.int32), (3, n, L))
+        pos, pp = self._i32(position_ids)
+        assert pos.shape == (3, n, L), pos.shape
+        nxt = np.empty(n, np.int32)
+        lg = np.empty((n, self.vlm_dims()["vocab"]), np.float32) if want_logits else None
+        self._ck(self.lib.fe_vlm_prefill(self.h, tp, pp, n, L, int(max_seq or min(8192, L + 256)), nxt.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         lg.ctypes.data_as(_f32p) if want_logits else None))
+        return (nxt, lg) if want_logits else nxt
+
+    def vlm_decode_step(self, tokens, position_ids, want_logits=False):
+        """tokens int [n_seq] (the tokens chosen at the previous step), position_ids int [3, n_seq]."""
+        tok, tp = self._i32(tokens)
+        pos, pp = self._i32(position_ids)
+        n = tok.shape[0]
+        assert pos.shape == (3, n), pos.shape
+        nxt = np.empty(n, np.int32)
+        lg = np.empty((n, self.vlm_dims()["vocab"]), np.float32) if want_logits else None
+        self._ck(self.lib.fe_vlm_decode_step(self.h, tp, pp, n, nxt.ctypes.data_as(C.POINTER(C.c_int32)), lg.ctypes.data_as(_f32p) if want_logits else None))
+        return (nxt, lg) if want_logits else nxt
+
+    def vlm_generate(self, tokens, max_new_tokens, position_ids=None, eos_token_ids=(), want_logits=False, forced_tokens=None):
+        """Greedy generation (`generate(..., do_sample=False)`, models/vlm_tagger.py:255-259): prefill + max_new_tokens - 1 decode
+        steps for all sequences in lockstep; a sequence that emitted an EOS id keeps receiving that id (what generate's padding does).
+        New positions continue from max(position_ids) + 1 per sequence. forced_tokens [n_seq, max_new_tokens]: teacher forcing - the
+        token FED at each step is taken from there instead of the engine's own choice (parity tests)."""
+        tok = np.ascontiguousarray(tokens, dtype=np.int32)
+        n, L = tok.shape
+        if position_ids is None:
+            position_ids = np.broadcast_to(np.arange(L, dtype=np.int32), (3, n, L))
+        position_ids = np.ascontiguousarray(position_ids, dtype=np.int32)
+        nxt_pos = position_ids.max(axis=(0, 2)) + 1            # [n_seq]
+        out = np.zeros((n, max_new_tokens), np.int32)
+        logits = []
+        r = self.vlm_prefill(tok, position_ids, max_seq=min(8192, L + max_new_tokens), want_logits=want_logits)
+        cur = r[0] if want_logits else r
+        done = np.zeros(n, bool)
+        eos = set(int(e) for e in eos_token_ids)
+        for step in range(max_new_tokens):
+            if want_logits:
+                logits.append(r[1])
+            out[:, step] = cur
+            done |= np.isin(cur, list(eos)) if eos else False
+            if step + 1 == max_new_tokens or done.all():
+                out[:, step + 1:] = cur[:, None] if done.all() else 0
+                break
+            feed = cur if forced_tokens is None else np.asarray(forced_tokens)[:, step].astype(np.int32)
+            r = self.vlm_decode_step(feed, np.broadcast_to(nxt_pos.astype(np.int32), (3, n)), want_logits=want_logits)
+            nxt_pos = nxt_pos + 1
+            new = r[0] if want_logits else r
+            cur = np.where(done, cur, new)
+        return (out, np.stack(logits, 1)) if want_logits else out
 
     # -- ONNX graphs (InsightFace sessions) -------------------------------------------------------------
     def graph_load(self, slot, onnx_bytes):

@@ -314,6 +314,7 @@ int fe_model_precision(fe_ctx* ctx, int model) {
   if (model == FE_MODEL_SAMP && ctx->c.samp) return code(ctx->c.samp->dw);
   if (model == FE_MODEL_CLIP && ctx->c.clip) return code(ctx->c.clip->dw);
   if (model == FE_MODEL_AESTHETIC && ctx->c.aesthetic) return FE_PRECISION_F32;
+  if (model == FE_MODEL_VLM && ctx->c.vlm) return FE_PRECISION_BF16;
   return -1;
 }
 
@@ -368,6 +369,10 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
     m->dw.prec = ctx->c.precision; m->dw.res32 = ctx->c.res32;
     build_sampnet(*m, ws);
     ctx->c.samp = std::move(m);
+  } else if (model == FE_MODEL_VLM) {
+    auto m = std::make_unique<VlmModel>();
+    build_vlm(*m, ws, ctx->c.vlm_cfg);      // always bf16: the precision the reference loads it in (models/vlm_tagger.py:155-156)
+    ctx->c.vlm = std::move(m);
   } else {
     throw Error("fe_weights_commit: model " + std::to_string(model) + " not implemented");
   }
@@ -383,6 +388,7 @@ int fe_model_unload(fe_ctx* ctx, int model) {
   if (model == FE_MODEL_SAMP) ctx->c.samp.reset();
   if (model == FE_MODEL_CLIP) { ctx->c.clip.reset(); ctx->c.clip_text.reset(); }
   if (model == FE_MODEL_AESTHETIC) ctx->c.aesthetic.reset();
+  if (model == FE_MODEL_VLM) ctx->c.vlm.reset();
   FE_API_END(ctx)
 }
 int fe_model_loaded(fe_ctx* ctx, int model) {
@@ -392,6 +398,7 @@ int fe_model_loaded(fe_ctx* ctx, int model) {
   if (model == FE_MODEL_SAMP) return ctx->c.samp != nullptr;
   if (model == FE_MODEL_CLIP) return ctx->c.clip != nullptr;
   if (model == FE_MODEL_AESTHETIC) return ctx->c.aesthetic != nullptr;
+  if (model == FE_MODEL_VLM) return ctx->c.vlm != nullptr;
   return 0;
 }
 
@@ -1230,6 +1237,66 @@ int fe_tag_similarities(fe_ctx* ctx, const float* emb, int n, const float* text,
   linear_forward(C, tw, d_e, d, n, d_s, T, ACT_NONE);
   FE_HIP(hipMemcpyAsync(sims, d_s, (size_t)n * T * sizeof(float), hipMemcpyDeviceToHost, C.stream));
   FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
+
+// ---- VLM tagger: text decoder of Qwen2.5-VL (models/vlm_tagger.py:163-184 load, :250-259 / :355-360 greedy generate) ----------------
+int fe_vlm_configure(fe_ctx* ctx, int n_heads, int n_kv_heads, int head_dim, float rope_theta, float rms_eps, const int* mrope_section) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0 && head_dim == 128 && rope_theta > 0.f && rms_eps > 0.f && mrope_section,
+           "vlm_configure: bad geometry (head_dim must be 128)");
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  VlmConfig& g = ctx->c.vlm_cfg;
+  g.n_heads = n_heads; g.n_kv_heads = n_kv_heads; g.head_dim = head_dim; g.rope_theta = rope_theta; g.rms_eps = rms_eps;
+  for (int i = 0; i < 3; ++i) g.mrope[i] = mrope_section[i];
+  FE_API_END(ctx)
+}
+int fe_vlm_dims(fe_ctx* ctx, int* dims) {
+  FE_API_BEGIN(ctx)
+  if (!ctx->c.vlm) { ctx->c.err = "vlm weights not loaded"; return FE_ERR_NOT_LOADED; }
+  FE_CHECK(dims, "bad arguments");
+  const VlmModel& m = *ctx->c.vlm;
+  dims[0] = m.vocab; dims[1] = m.hidden; dims[2] = (int)m.layers.size(); dims[3] = m.cfg.n_heads; dims[4] = m.cfg.n_kv_heads; dims[5] = m.inter;
+  dims[6] = m.max_seq; dims[7] = m.cur_len;
+  FE_API_END(ctx)
+}
+extern "C++" {
+// tokens (+ optional replacement rows for image tokens) -> embeddings -> decoder -> next tokens; shared by prefill and decode
+static void vlm_step(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int len, int32_t* next_tokens, float* logits) {
+  Ctx& C = ctx->c;
+  VlmModel& m = *C.vlm;
+  const int rows = n_seq * len;
+  C.arena.reset();
+  int* d_tok = (int*)C.arena.alloc((size_t)rows * sizeof(int));
+  int* d_pos = (int*)C.arena.alloc((size_t)3 * rows * sizeof(int));
+  int* d_next = (int*)C.arena.alloc((size_t)n_seq * sizeof(int));
+  float* d_logits = logits ? (float*)C.arena.alloc((size_t)n_seq * m.vocab * sizeof(float)) : nullptr;
+  bf16* x = C.arena.array<bf16>((size_t)rows * m.hidden);
+  FE_HIP(hipMemcpyAsync(d_tok, tokens, (size_t)rows * sizeof(int), hipMemcpyHostToDevice, C.stream));
+  FE_HIP(hipMemcpyAsync(d_pos, position_ids, (size_t)3 * rows * sizeof(int), hipMemcpyHostToDevice, C.stream));
+  vlm_embed(C, m, d_tok, rows, x);
+  vlm_forward(C, m, x, d_pos, n_seq, len, d_next, d_logits);
+  FE_HIP(hipMemcpyAsync(next_tokens, d_next, (size_t)n_seq * sizeof(int), hipMemcpyDeviceToHost, C.stream));
+  if (logits) FE_HIP(hipMemcpyAsync(logits, d_logits, (size_t)n_seq * m.vocab * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+}
+}  // extern "C++"
+int fe_vlm_prefill(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int len, int max_seq, int32_t* next_tokens, float* logits) {
+  FE_API_BEGIN(ctx)
+  if (!ctx->c.vlm) { ctx->c.err = "vlm weights not loaded"; return FE_ERR_NOT_LOADED; }
+  FE_CHECK(tokens && position_ids && next_tokens && n_seq > 0 && len > 0 && max_seq >= len && max_seq <= 8192, "bad arguments (max_seq <= 8192)");
+  ctx->c.vlm->reserve_cache(n_seq, max_seq);
+  ctx->c.vlm->cur_len = 0;
+  vlm_step(ctx, tokens, position_ids, n_seq, len, next_tokens, logits);
+  FE_API_END(ctx)
+}
+int fe_vlm_decode_step(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int32_t* next_tokens, float* logits) {
+  FE_API_BEGIN(ctx)
+  if (!ctx->c.vlm) { ctx->c.err = "vlm weights not loaded"; return FE_ERR_NOT_LOADED; }
+  VlmModel& m = *ctx->c.vlm;
+  FE_CHECK(tokens && position_ids && next_tokens && n_seq == m.cache_B && m.cur_len > 0, "decode_step: call fe_vlm_prefill for these %d sequences first", n_seq);
+  FE_CHECK(m.cur_len < m.max_seq, "decode_step: the KV cache is full (%d positions)", m.max_seq);
+  vlm_step(ctx, tokens, position_ids, n_seq, 1, next_tokens, logits);
   FE_API_END(ctx)
 }
 

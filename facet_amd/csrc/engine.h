@@ -29,6 +29,7 @@ class DeviceWeights {
  public:
   int prec = 0;   // Precision the owning model is built for: pack_conv also emits the 2-byte forms (bf16 / f16) when it is not PREC_F32
   bool res32 = false;   // FE_PRECISION_RES32: the model keeps its residual / skip streams in fp32 around 2-byte GEMM operands
+  bool half_only = false;   // 2-byte models whose every layer has a 2-byte form (the VLM decoder): no fp32 / Winograd / tap copies uploaded
   ~DeviceWeights() { release(); }
   float* upload(const std::vector<float>& v);
   void* upload_raw(const void* data, size_t bytes);   // any element type (bf16 weights)
@@ -187,6 +188,9 @@ void resize_u8(Ctx& c, const uint8_t* d_src, int n, int h, int w, int oh, int ow
 class Graph;   // onnx_graph.h
 struct GraphSlot;
 
+// geometry the checkpoint's tensor shapes do not determine (transformers Qwen2_5_VLTextConfig): defaults = Qwen2.5-VL-7B-Instruct
+struct VlmConfig { int n_heads = 28, n_kv_heads = 4, head_dim = 128; float rope_theta = 1e6f, rms_eps = 1e-6f; int mrope[3] = {16, 24, 24}; };
+
 struct OpTiming { std::string name; double flops; double bytes; float ms; };
 
 struct Ctx {
@@ -216,6 +220,8 @@ struct Ctx {
   std::unique_ptr<struct ClipModel> clip;
   std::unique_ptr<struct AestheticModel> aesthetic;
   std::unique_ptr<struct ClipTextModel> clip_text;
+  std::unique_ptr<struct VlmModel> vlm;
+  VlmConfig vlm_cfg;          // read by the next fe_weights_commit(FE_MODEL_VLM) (fe_vlm_configure)
   std::unique_ptr<GraphSlot> graphs[8];   // ONNX graphs (face detector / landmarks / recognition, ...)
   ~Ctx();
 };
@@ -301,6 +307,26 @@ template <class T, class RT = T>
 void clip_forward(Ctx& c, const ClipModel& m, const Tensor& x_nhwc4, float* feat);
 void aesthetic_forward(Ctx& c, const AestheticModel& m, const float* feat, int B, float* raw);
 void l2_normalize(Ctx& c, const float* x, float* y, int rows, int d);
+
+// ---- VLM tagger text decoder (transformers Qwen2_5_VLForConditionalGeneration; reference models/vlm_tagger.py) - model_vlm.hip ----------
+struct VlmLayerW { ConvW qkv, o, gate, up, down; bf16* ln1 = nullptr; bf16* ln2 = nullptr; };
+struct VlmModel {
+  DeviceWeights dw;
+  VlmConfig cfg;
+  bf16* embed = nullptr; bf16* norm = nullptr; float* inv_freq = nullptr;
+  ConvW lm_head;
+  std::vector<VlmLayerW> layers;
+  int vocab = 0, hidden = 0, inter = 0;
+  // contiguous KV cache: per layer [n_seq][n_kv_heads][max_seq][128] keys (rotated) and values
+  std::vector<bf16*> kcache, vcache;
+  int cache_B = 0, max_seq = 0, cur_len = 0;
+  void reserve_cache(int B, int max_seq);
+  void release_cache();
+  ~VlmModel() { release_cache(); }
+};
+void build_vlm(VlmModel& m, const WeightStore& ws, const VlmConfig& cfg);
+void vlm_embed(Ctx& c, const VlmModel& m, const int* tok_dev, int rows, bf16* x);
+void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int* next_dev, float* logits_dev);
 
 void build_topiq_head(TopiqModel& m, const WeightStore& ws);
 // feats: the 5 pyramid levels for nb images; scores_dev: device [nb]

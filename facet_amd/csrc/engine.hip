@@ -82,8 +82,10 @@ ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>
           const size_t k = blocked ? ((size_t)(ci / 16) * ntaps + tap) * 16 + (ci % 16) : (size_t)tap * c.CinPad + ci;
           packed[(size_t)co * c.Kp + k] = w.data[(((size_t)co * c.Cin + ci) * c.KH + kh) * c.KW + kw];
         }
-  c.w = dw.upload(packed);
-  if (c.Cout <= 2 && c.KH * c.KW > 1 && c.CinPad % 16 == 0) {
+  // (half_only models: the 2-byte form below is the only one their layers run on)
+  const bool skip_f32 = dw.half_only && dw.prec != PREC_F32 && (c.KH * c.KW == 1 || ((c.Cin + 7) & ~7) % 16 == 0);
+  if (!skip_f32) c.w = dw.upload(packed);
+  if (!skip_f32 && c.Cout <= 2 && c.KH * c.KW > 1 && c.CinPad % 16 == 0) {
     // tap-decomposed form: z[pixel][tap*Cout+co] = <x[pixel], w[co][tap]> as a 1x1 conv, neighbours summed afterwards
     const int T = c.KH * c.KW * c.Cout;
     c.KpT = (c.CinPad + CONV_KALIGN - 1) / CONV_KALIGN * CONV_KALIGN;
@@ -110,7 +112,7 @@ ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>
   }
   static const int wino_min_cin = getenv("FE_WINO_MIN_CIN") ? atoi(getenv("FE_WINO_MIN_CIN")) : 96;   // tuning hooks; defaults measured best (profiles/r01_README.md)
   static const int wino_form = getenv("FE_WINO_FORM") ? atoi(getenv("FE_WINO_FORM")) : 4;
-  if ((wino_form == 2 || wino_form == 4) && c.KH == 3 && c.KW == 3 && c.Cin == c.CinPad && c.Cin % 32 == 0 && c.Cin >= wino_min_cin && c.Cout % 4 == 0) {
+  if (!skip_f32 && (wino_form == 2 || wino_form == 4) && c.KH == 3 && c.KW == 3 && c.Cin == c.CinPad && c.Cin % 32 == 0 && c.Cin >= wino_min_cin && c.Cout % 4 == 0) {
     // Winograd weights U = G g G^T per (cout, cin), in double. Layout [planes][Cout][Cin]; the epilogue scale / shift / activation
     // are applied by the output transform (ConvW.scale may be attached after packing).
     static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};

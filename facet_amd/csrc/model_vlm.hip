@@ -1,0 +1,455 @@
+// VLM tagger, slice 1: the text decoder of Qwen2.5-VL (SURVEY 8(f)-4 / BASELINE configs[4]) - prefill + single-token decode with a
+// contiguous KV cache, greedy next-token selection.
+//
+// Stands behind reference models/vlm_tagger.py: `Qwen2_5_VLForConditionalGeneration.from_pretrained(..., dtype=torch.bfloat16)`
+// (:163-184) and `self.model.generate(**inputs, max_new_tokens=..., do_sample=False)` (:250-259, :355-360). The arithmetic is
+// transformers' (modeling_qwen2_5_vl.py: Qwen2_5_VLDecoderLayer = RMSNorm -> q/k/v projections with bias -> multimodal rotary
+// embedding (sections 16/24/24 over the 64 frequency pairs of head_dim 128) -> grouped-query causal attention -> o_proj -> residual ->
+// RMSNorm -> SwiGLU MLP -> residual; final RMSNorm; untied lm_head), restated here in the precision the reference loads: bf16 storage
+// of every activation with the SAME rounding points as the bf16 torch modules (each Linear output, RMSNorm's normalised value before the
+// weight multiply, both products of the rotary embedding, SiLU before the gate multiply, each residual sum, the logits), fp32
+// accumulation inside every contraction. Parity: tests/test_vlm_gpu.py against vectors of the reference's own model class
+// (tests/golden/make_vlm_golden.py) - pinned.
+// Not in this slice: the vision tower (window attention, patch merger) and fp8 attention; image tokens enter as rows of `embeds`.
+#include "engine.h"
+#include <cmath>
+
+namespace fe {
+
+// ---- small row kernels ------------------------------------------------------------------------------------------------------------
+// x[row][:] = E[tok[row]][:]   (bf16 table)
+__global__ void vlm_embed_kernel(const int* __restrict__ tok, const bf16* __restrict__ E, bf16* __restrict__ x, int rows, int d, int vocab) {
+  const size_t total = (size_t)rows * (d / 8);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / (d / 8)), c = (int)(i % (d / 8)) * 8;
+    int t = tok[row];
+    t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+    *reinterpret_cast<uint4*>(x + (size_t)row * d + c) = *reinterpret_cast<const uint4*>(E + (size_t)t * d + c);
+  }
+}
+
+// transformers' RMSNorm in bf16: x32 = float(x); y = w * bf16(x32 * rsqrt(mean(x32^2) + eps)), the product rounded to bf16.
+// One wave per row; d % 8 == 0.
+__global__ void vlm_rmsnorm_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w, bf16* __restrict__ y, int ldy, int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int row = wave; row < rows; row += nwaves) {
+    const bf16* xr = x + (size_t)row * ldx;
+    float ss = 0.f;
+    for (int i = lane * 4; i < d; i += 256) { const float4 v = ld4(xr + i); ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rs = rsqrtf(ss / (float)d + eps);
+    bf16* yr = y + (size_t)row * ldy;
+    for (int i = lane * 4; i < d; i += 256) {
+      const float4 v = ld4(xr + i), g = ld4(w + i);
+      st4(yr + i, make_float4(g.x * (float)(bf16)(v.x * rs), g.y * (float)(bf16)(v.y * rs), g.z * (float)(bf16)(v.z * rs), g.w * (float)(bf16)(v.w * rs)));
+    }
+  }
+}
+
+// Multimodal rotary embedding on the q and k heads of a fused QKV row block + the KV-cache append.
+//   qkv: [rows][(nh + 2 nkv) * 128]; pos: [3][rows] (temporal, height, width position of every token; equal for text tokens)
+//   q_out: [rows][nh * 128]; kc / vc: cache [B][nkv][max_seq][128], row `row` = (b, t) lands at position start + t.
+// Dimension i of a head takes frequency i % 64 and the position component of its section (sections doubled over the two halves:
+// [16, 24, 24, 16, 24, 24]); cos / sin are rounded to bf16 and x*cos, rotate_half(x)*sin and their sum are each rounded to bf16, as
+// apply_multimodal_rotary_pos_emb does on bf16 tensors. One thread per (row, head, pair d < 64).
+__global__ void vlm_rope_cache_kernel(const bf16* __restrict__ qkv, const int* __restrict__ pos, const float* __restrict__ inv_freq, bf16* __restrict__ q_out,
+                                      bf16* __restrict__ kc, bf16* __restrict__ vc, int rows, int L, int nh, int nkv, int s0, int s1, int start, int max_seq) {
+  const int heads = nh + 2 * nkv;
+  const size_t total = (size_t)rows * heads * 64;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i & 63), hd = (int)((i >> 6) % heads), row = (int)(i / ((size_t)heads * 64));
+    const bf16* src = qkv + ((size_t)row * heads + hd) * 128;
+    const int b = row / L, t = row - b * L;
+    if (hd >= nh + nkv) {      // V: plain copy into the cache
+      bf16* dst = vc + (((size_t)b * nkv + (hd - nh - nkv)) * max_seq + start + t) * 128;
+      dst[d] = src[d]; dst[d + 64] = src[d + 64];
+      continue;
+    }
+    const int comp = d < s0 ? 0 : (d < s0 + s1 ? 1 : 2);
+    const float ang = (float)pos[(size_t)comp * rows + row] * inv_freq[d];
+    const float c = (float)(bf16)cosf(ang), s = (float)(bf16)sinf(ang);
+    const float x1 = (float)src[d], x2 = (float)src[d + 64];
+    const bf16 o1 = (bf16)((float)(bf16)(x1 * c) + (float)(bf16)(-x2 * s));
+    const bf16 o2 = (bf16)((float)(bf16)(x2 * c) + (float)(bf16)(x1 * s));
+    bf16* dst = hd < nh ? q_out + ((size_t)row * nh + hd) * 128 : kc + (((size_t)b * nkv + (hd - nh)) * max_seq + start + t) * 128;
+    dst[d] = o1; dst[d + 64] = o2;
+  }
+}
+
+// h = bf16(bf16(silu(g)) * u)   (Qwen2MLP: act_fn(gate_proj(x)) * up_proj(x) on bf16 tensors)
+__global__ void vlm_silu_mul_kernel(const bf16* g, const bf16* __restrict__ u, bf16* h, size_t n4) {      // h may be g
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = ld4(g + 4 * i), b = ld4(u + 4 * i);
+    auto f = [](float x, float y) { return (float)(bf16)(x / (1.f + expf(-x))) * y; };
+    st4(h + 4 * i, make_float4(f(a.x, b.x), f(a.y, b.y), f(a.z, b.z), f(a.w, b.w)));
+  }
+}
+// x = bf16(x + y)
+__global__ void vlm_add_kernel(bf16* __restrict__ x, const bf16* __restrict__ y, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = ld4(x + 4 * i), b = ld4(y + 4 * i);
+    st4(x + 4 * i, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+  }
+}
+// last[b][:] = x[b * L + L - 1][:]
+__global__ void vlm_last_rows_kernel(const bf16* __restrict__ x, bf16* __restrict__ last, int B, int L, int d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * d) return;
+  const int b = i / d, c = i - b * d;
+  last[i] = x[((size_t)b * L + L - 1) * d + c];
+}
+// logits rounded to bf16 (what lm_head emits on a bf16 model), widened back into `lg`; next[b] = first index of the row maximum
+// (torch.argmax's tie rule on equal bf16 values). One block per row.
+__global__ void vlm_argmax_kernel(float* __restrict__ lg, int vocab, int* __restrict__ next) {
+  float* row = lg + (size_t)blockIdx.x * vocab;
+  float best = -INFINITY; int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < vocab; i += blockDim.x) {
+    const float v = (float)(bf16)row[i];
+    row[i] = v;
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+  __shared__ float sv[256]; __shared__ int si[256];
+  sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const float v = sv[threadIdx.x + o]; const int j = si[threadIdx.x + o];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && j < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = j; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) next[blockIdx.x] = si[0];
+}
+
+// ---- prefill attention: causal, grouped-query, head_dim 128, on the bf16 matrix cores --------------------------------------------------
+// One wave owns 32 queries; a workgroup (4 waves = 128 queries) shares 32-key K / V tiles through LDS. Same scheme as
+// kernels_attn_bf16.hip (S^T = K Q^T with one query per accumulator column, online softmax per lane, the exponentiated accumulator
+// rounded to bf16 IS the B operand of O^T += V^T P^T), with 8 k-steps per S tile and four 32-row d-tiles of O. K / V come straight from
+// the cache rows ([pos][128]); V is transposed on its way into LDS (two-byte scatter), K rows are copied as they are.
+constexpr int VA_KS = 272;      // K tile row stride in bytes (256 + 16: conflict-free 16-byte reads over rows distinct mod 16... )
+constexpr int VA_VS = 72;       // V^T tile row stride in bytes (64 + 8)
+struct VlmAttnParams {
+  const bf16* q; int ldq;       // [B*Lq][nh*128]
+  const bf16* kc; const bf16* vc;   // caches [B][nkv][max_seq][128]
+  bf16* o; int ldo;             // [B*Lq][nh*128]
+  int B, nh, nkv, Lq, Lk, max_seq, qpos0;      // query i sits at sequence position qpos0 + i and sees keys 0 .. qpos0 + i
+  float scale;
+};
+union VA8 { uint4 u; fe_v4f f; };
+
+__global__ __launch_bounds__(256, 2) void vlm_attn_prefill_kernel(const VlmAttnParams p) {
+  __shared__ __attribute__((aligned(16))) char Ks[2][32 * VA_KS];
+  __shared__ __attribute__((aligned(16))) char Vs[2][128 * VA_VS];
+  const bf16* const tag = nullptr;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / p.nh, head = bh - b * p.nh, kvh = head / (p.nh / p.nkv);
+  const bf16* Qp = p.q + (size_t)b * p.Lq * p.ldq + head * 128;
+  const bf16* Kp = p.kc + ((size_t)b * p.nkv + kvh) * p.max_seq * 128;
+  const bf16* Vp = p.vc + ((size_t)b * p.nkv + kvh) * p.max_seq * 128;
+  const int q = (blockIdx.x * 4 + wave) * 32 + r;
+  const bool qok = q < p.Lq;
+  const int qc = qok ? q : p.Lq - 1;
+  const int qpos = p.qpos0 + q;
+  VA8 qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) qf[s].u = *reinterpret_cast<const uint4*>(Qp + (size_t)qc * p.ldq + 16 * s + 8 * h);
+  // this workgroup's queries end at position qpos0 + (blockIdx.x + 1) * 128 - 1: later keys are masked for all of them
+  const int kend = min(p.Lk, p.qpos0 + (int)(blockIdx.x + 1) * 128);
+  const int nt = (kend + 31) / 32;
+  uint4 kr[2], vr[2];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = t + i * 256;                 // 512 chunks of 16 B: key = c >> 4, d = (c & 15) * 8
+      int key = kt * 32 + (c >> 4);
+      if (key > p.Lk - 1) key = p.Lk - 1;        // masked after QK^T
+      kr[i] = *reinterpret_cast<const uint4*>(Kp + (size_t)key * 128 + (c & 15) * 8);
+      vr[i] = *reinterpret_cast<const uint4*>(Vp + (size_t)key * 128 + (c & 15) * 8);
+    }
+  };
+  auto store_tile = [&](int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = t + i * 256, key = c >> 4, d0 = (c & 15) * 8;
+      *reinterpret_cast<uint4*>(&Ks[buf][key * VA_KS + d0 * 2]) = kr[i];
+      const bool live = kt * 32 + key < p.Lk;   // keys past Lk contribute zero rows of V (their probabilities are zero anyway)
+      const unsigned w[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned short v = live ? (unsigned short)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xFFFFu)) : (unsigned short)0;
+        *reinterpret_cast<unsigned short*>(&Vs[buf][(d0 + e) * VA_VS + key * 2]) = v;
+      }
+    }
+  };
+  fe_f32x16 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  load_tile(0);
+  store_tile(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nt) load_tile(kt + 1);
+    fe_f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+    const char* kb = &Ks[buf][r * VA_KS + 16 * h];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      VA8 kf;
+      kf.u = *reinterpret_cast<const uint4*>(kb + 32 * s);
+      st = fe_mfma16(tag, kf.f, qf[s].f, st);
+    }
+    const int kbase = kt * 32 + 4 * h;
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = kbase + (e & 3) + 8 * (e >> 2);
+      st[e] = (key >= p.Lk || key > qpos) ? -INFINITY : st[e] * p.scale;
+      tmax = fmaxf(tmax, st[e]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float mn = fmaxf(m, tmax);
+    const float msafe = mn == -INFINITY ? 0.f : mn;      // a query row whose keys so far are all masked (rows past Lq only)
+    const float alpha = __expf(m - msafe);
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st[e] = __expf(st[e] - msafe); psum += st[e]; }
+    psum += __shfl_xor(psum, 32);
+    l = l * alpha + psum;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+    const char* vb = &Vs[buf][r * VA_VS + 8 * h];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      VA8 pf;
+      pf.u = make_uint4(fe_pack2(tag, st[8 * s], st[8 * s + 1]), fe_pack2(tag, st[8 * s + 2], st[8 * s + 3]),
+                        fe_pack2(tag, st[8 * s + 4], st[8 * s + 5]), fe_pack2(tag, st[8 * s + 6], st[8 * s + 7]));
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint2 a0 = *reinterpret_cast<const uint2*>(vb + dt * 32 * VA_VS + 32 * s), a1 = *reinterpret_cast<const uint2*>(vb + dt * 32 * VA_VS + 32 * s + 16);
+        VA8 v;
+        v.u = make_uint4(a0.x, a0.y, a1.x, a1.y);
+        o[dt] = fe_mfma16(tag, v.f, pf.f, o[dt]);
+      }
+    }
+    if (kt + 1 < nt) store_tile(buf ^ 1, kt + 1);
+    __syncthreads();
+  }
+  if (qok) {
+    const float inv = 1.f / l;
+    bf16* op = p.o + ((size_t)b * p.Lq + q) * p.ldo + head * 128;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        st4(op + dt * 32 + 8 * g + 4 * h, make_float4(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv));
+  }
+}
+
+// ---- decode attention: one query per (sequence, head) over the whole cache - a pure streaming pass over K then V (HBM-bound: the
+// keys and values of a head are read once per step). One workgroup per (b, head): scores -> LDS, softmax, weighted sum of V rows.
+__global__ __launch_bounds__(256) void vlm_attn_decode_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kc, const bf16* __restrict__ vc, bf16* __restrict__ o,
+                                                              int nh, int nkv, int Lk, int max_seq, float scale) {
+  extern __shared__ float sc[];        // [Lk] scores / probabilities, then 4 x 128 partial outputs
+  __shared__ float qs[128];
+  __shared__ float red[8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.x / nh, head = blockIdx.x - b * nh, kvh = head / (nh / nkv);
+  const bf16* K = kc + ((size_t)b * nkv + kvh) * max_seq * 128;
+  const bf16* V = vc + ((size_t)b * nkv + kvh) * max_seq * 128;
+  if (t < 128) qs[t] = (float)q[((size_t)b * nh + head) * 128 + t];
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int key = t; key < Lk; key += 256) {
+    const bf16* kr = K + (size_t)key * 128;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float v[8];
+      const uint4 u = *reinterpret_cast<const uint4*>(kr + 8 * c);
+      fe_unpack2((const bf16*)nullptr, u.x, v[0], v[1]); fe_unpack2((const bf16*)nullptr, u.y, v[2], v[3]);
+      fe_unpack2((const bf16*)nullptr, u.z, v[4], v[5]); fe_unpack2((const bf16*)nullptr, u.w, v[6], v[7]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += v[e] * qs[8 * c + e];
+    }
+    acc *= scale;
+    sc[key] = acc;
+    mx = fmaxf(mx, acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int key = t; key < Lk; key += 256) { const float e = __expf(sc[key] - mx); sc[key] = e; sum += e; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+  // O: lane owns dims 2 lane, 2 lane + 1; wave w takes keys w, w + 4, ...; probabilities rounded to bf16 like the P operand of the
+  // matrix-core path
+  float a0 = 0.f, a1 = 0.f;
+  for (int key = wave; key < Lk; key += 4) {
+    const float pj = (float)(bf16)(sc[key] * inv);
+    const unsigned u = *reinterpret_cast<const unsigned*>(V + (size_t)key * 128 + 2 * lane);
+    float v0, v1;
+    fe_unpack2((const bf16*)nullptr, u, v0, v1);
+    a0 += pj * v0; a1 += pj * v1;
+  }
+  __syncthreads();      // everyone is done with sc[] as probabilities
+  float* part = sc;     // reuse: [4][128]
+  part[wave * 128 + 2 * lane] = a0; part[wave * 128 + 2 * lane + 1] = a1;
+  __syncthreads();
+  if (t < 128) o[((size_t)b * nh + head) * 128 + t] = (bf16)(part[t] + part[128 + t] + part[256 + t] + part[384 + t]);
+}
+
+// ---- model ---------------------------------------------------------------------------------------------------------------------------
+static bf16* upload_bf16(DeviceWeights& dw, const std::vector<float>& v) {
+  std::vector<uint16_t> h(v.size());
+  for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_bf16_bits(v[i]);
+  return (bf16*)dw.upload_raw(h.data(), h.size() * sizeof(uint16_t));
+}
+
+void build_vlm(VlmModel& m, const WeightStore& ws, const VlmConfig& cfg) {
+  m.cfg = cfg;
+  m.dw.prec = PREC_BF16;
+  m.dw.half_only = true;      // 7.6 G parameters: no fp32 / Winograd copies beside the bf16 ones
+  const std::string P = "model.language_model.";
+  const HostTensor& E = ws.get(P + "embed_tokens.weight");
+  m.vocab = (int)E.shape[0]; m.hidden = (int)E.shape[1];
+  FE_CHECK(cfg.head_dim == 128, "vlm: head_dim %d (the attention kernels are built for 128)", cfg.head_dim);
+  FE_CHECK(cfg.n_heads > 0 && cfg.n_kv_heads > 0 && cfg.n_heads % cfg.n_kv_heads == 0, "vlm: %d heads / %d kv heads", cfg.n_heads, cfg.n_kv_heads);
+  FE_CHECK(cfg.mrope[0] + cfg.mrope[1] + cfg.mrope[2] == 64, "vlm: mrope sections must sum to head_dim / 2");
+  FE_CHECK(m.hidden % 64 == 0, "vlm: hidden size %d must be a multiple of 64", m.hidden);
+  m.embed = upload_bf16(m.dw, E.data);
+  m.layers.clear();
+  const int qd = cfg.n_heads * 128, kd = cfg.n_kv_heads * 128;
+  for (int i = 0;; ++i) {
+    const std::string L = P + "layers." + std::to_string(i);
+    if (!ws.has(L + ".self_attn.q_proj.weight")) break;
+    VlmLayerW w;
+    // q | k | v as ONE projection: rows concatenated, biases concatenated
+    HostTensor W, Bv;
+    W.shape = {qd + 2 * kd, m.hidden}; Bv.shape = {qd + 2 * kd};
+    for (const char* n : {"q_proj", "k_proj", "v_proj"}) {
+      const HostTensor& a = ws.get(L + ".self_attn." + n + ".weight");
+      const HostTensor& bb = ws.get(L + ".self_attn." + n + ".bias");
+      FE_CHECK((int)a.shape[1] == m.hidden, "vlm: %s input width", n);
+      W.data.insert(W.data.end(), a.data.begin(), a.data.end());
+      Bv.data.insert(Bv.data.end(), bb.data.begin(), bb.data.end());
+    }
+    FE_CHECK((int64_t)W.data.size() == W.shape[0] * W.shape[1], "vlm: layer %d q/k/v shapes do not match %d heads / %d kv heads of 128", i, cfg.n_heads, cfg.n_kv_heads);
+    w.qkv = build_linear_rows(m.dw, W, &Bv, 0, qd + 2 * kd);
+    w.o = build_linear(m.dw, ws, L + ".self_attn.o_proj", false);
+    w.gate = build_linear(m.dw, ws, L + ".mlp.gate_proj", false);
+    w.up = build_linear(m.dw, ws, L + ".mlp.up_proj", false);
+    w.down = build_linear(m.dw, ws, L + ".mlp.down_proj", false);
+    w.ln1 = upload_bf16(m.dw, ws.get(L + ".input_layernorm.weight").data);
+    w.ln2 = upload_bf16(m.dw, ws.get(L + ".post_attention_layernorm.weight").data);
+    m.layers.push_back(w);
+  }
+  FE_CHECK(!m.layers.empty(), "vlm: no decoder layers found");
+  m.norm = upload_bf16(m.dw, ws.get(P + "norm.weight").data);
+  m.lm_head = build_linear(m.dw, ws, "lm_head", false);
+  m.inter = m.layers[0].gate.Cout;
+  // inv_freq as Qwen2_5_VLRotaryEmbedding.compute_default_rope_parameters: 1 / base^(2i / dim), fp32
+  std::vector<float> inv(64);
+  for (int i = 0; i < 64; ++i) inv[i] = 1.0f / powf(cfg.rope_theta, (float)(2 * i) / 128.0f);
+  m.inv_freq = m.dw.upload(inv);
+}
+
+void VlmModel::reserve_cache(int B, int max_seq_) {
+  const size_t per = (size_t)B * cfg.n_kv_heads * max_seq_ * 128;
+  if (B == cache_B && max_seq_ == max_seq && !kcache.empty()) return;
+  release_cache();
+  for (size_t i = 0; i < layers.size(); ++i) {
+    void *k = nullptr, *v = nullptr;
+    FE_HIP(hipMalloc(&k, per * sizeof(bf16)));
+    kcache.push_back((bf16*)k);
+    FE_HIP(hipMalloc(&v, per * sizeof(bf16)));
+    vcache.push_back((bf16*)v);
+  }
+  cache_B = B; max_seq = max_seq_; cur_len = 0;
+}
+void VlmModel::release_cache() {
+  for (bf16* p : kcache) (void)hipFree(p);
+  for (bf16* p : vcache) (void)hipFree(p);
+  kcache.clear(); vcache.clear();
+  cache_B = 0; max_seq = 0; cur_len = 0;
+}
+
+static inline int grid_n(size_t n, int per = 256) { size_t g = (n + per - 1) / per; return (int)(g > 65535 * 4 ? 65535 * 4 : (g ? g : 1)); }
+
+// x: [B*L][hidden] bf16 rows (token embeddings, image rows already in place), pos: device [3][B*L]. Appends L positions to the cache of
+// every sequence, leaves the next token of every sequence in next_dev [B] and (optionally) the bf16-rounded logits in logits_dev [B][vocab].
+void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int* next_dev, float* logits_dev) {
+  const VlmConfig& g = m.cfg;
+  const int rows = B * L, d = m.hidden, nh = g.n_heads, nkv = g.n_kv_heads, qd = nh * 128, qkvd = (nh + 2 * nkv) * 128;
+  const int start = m.cur_len, Lk = start + L;
+  FE_CHECK(B == m.cache_B && Lk <= m.max_seq, "vlm: %d sequences x %d positions do not fit the cache (%d x %d)", B, Lk, m.cache_B, m.max_seq);
+  const size_t mark = c.arena.mark();
+  bf16* n = c.arena.array<bf16>((size_t)rows * d);
+  bf16* qkv = c.arena.array<bf16>((size_t)rows * qkvd);
+  bf16* qr = c.arena.array<bf16>((size_t)rows * qd);
+  bf16* ao = c.arena.array<bf16>((size_t)rows * qd);
+  bf16* br = c.arena.array<bf16>((size_t)rows * d);
+  bf16* gg = c.arena.array<bf16>((size_t)rows * m.inter);
+  bf16* uu = c.arena.array<bf16>((size_t)rows * m.inter);
+  const float scale = 1.0f / sqrtf(128.f);
+  for (size_t li = 0; li < m.layers.size(); ++li) {
+    const VlmLayerW& w = m.layers[li];
+    hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, (const bf16*)x, d, (const bf16*)w.ln1, n, d, rows, d, g.rms_eps);
+    linear_forward(c, w.qkv, (const bf16*)n, d, rows, qkv, qkvd, ACT_NONE);
+    hipLaunchKernelGGL(vlm_rope_cache_kernel, dim3(grid_n((size_t)rows * (nh + 2 * nkv) * 64)), dim3(256), 0, c.stream, (const bf16*)qkv, pos, (const float*)m.inv_freq, qr,
+                       m.kcache[li], m.vcache[li], rows, L, nh, nkv, g.mrope[0], g.mrope[1], start, m.max_seq);
+    if (L == 1) {
+      hipLaunchKernelGGL(vlm_attn_decode_kernel, dim3(B * nh), dim3(256), (size_t)std::max(Lk, 512) * sizeof(float), c.stream, (const bf16*)qr, (const bf16*)m.kcache[li],
+                         (const bf16*)m.vcache[li], ao, nh, nkv, Lk, m.max_seq, scale);
+    } else {
+      VlmAttnParams ap{qr, qd, m.kcache[li], m.vcache[li], ao, qd, B, nh, nkv, L, Lk, m.max_seq, start, scale};
+      hipLaunchKernelGGL(vlm_attn_prefill_kernel, dim3((L + 127) / 128, B * nh), dim3(256), 0, c.stream, ap);
+    }
+    FE_HIP(hipGetLastError());
+    c.flops_accum += 4.0 * B * nh * (double)L * (start + (L + 1) * 0.5) * 128;
+    c.flops_half += 4.0 * B * nh * (double)L * (start + (L + 1) * 0.5) * 128;
+    linear_forward(c, w.o, (const bf16*)ao, qd, rows, br, d, ACT_NONE);
+    hipLaunchKernelGGL(vlm_add_kernel, dim3(grid_n((size_t)rows * d / 4)), dim3(256), 0, c.stream, x, (const bf16*)br, (size_t)rows * d / 4);
+    hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, (const bf16*)x, d, (const bf16*)w.ln2, n, d, rows, d, g.rms_eps);
+    linear_forward(c, w.gate, (const bf16*)n, d, rows, gg, m.inter, ACT_NONE);
+    linear_forward(c, w.up, (const bf16*)n, d, rows, uu, m.inter, ACT_NONE);
+    hipLaunchKernelGGL(vlm_silu_mul_kernel, dim3(grid_n((size_t)rows * m.inter / 4)), dim3(256), 0, c.stream, (const bf16*)gg, (const bf16*)uu, gg, (size_t)rows * m.inter / 4);
+    linear_forward(c, w.down, (const bf16*)gg, m.inter, rows, br, d, ACT_NONE);
+    hipLaunchKernelGGL(vlm_add_kernel, dim3(grid_n((size_t)rows * d / 4)), dim3(256), 0, c.stream, x, (const bf16*)br, (size_t)rows * d / 4);
+    FE_HIP(hipGetLastError());
+  }
+  // final norm + lm_head on the last position of every sequence
+  bf16* last = c.arena.array<bf16>((size_t)B * d);
+  bf16* lastn = c.arena.array<bf16>((size_t)B * d);
+  hipLaunchKernelGGL(vlm_last_rows_kernel, dim3((B * d + 255) / 256), dim3(256), 0, c.stream, (const bf16*)x, last, B, L, d);
+  hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)B * 64)), dim3(256), 0, c.stream, (const bf16*)last, d, (const bf16*)m.norm, lastn, d, B, d, g.rms_eps);
+  float* lg = logits_dev ? logits_dev : c.arena.array<float>((size_t)B * m.vocab);
+  linear_forward_f32(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab, ACT_NONE);
+  hipLaunchKernelGGL(vlm_argmax_kernel, dim3(B), dim3(256), 0, c.stream, lg, m.vocab, next_dev);
+  FE_HIP(hipGetLastError());
+  m.cur_len = Lk;
+  c.arena.rewind(mark);
+}
+
+void vlm_embed(Ctx& c, const VlmModel& m, const int* tok_dev, int rows, bf16* x) {
+  hipLaunchKernelGGL(vlm_embed_kernel, dim3(grid_n((size_t)rows * m.hidden / 8)), dim3(256), 0, c.stream, tok_dev, (const bf16*)m.embed, x, rows, m.hidden, m.vocab);
+  FE_HIP(hipGetLastError());
+}
+
+}  // namespace fe

@@ -221,7 +221,35 @@ def sampnet_spec():
     return spec
 
 
+def qwen2_5_vl_text_spec(hidden=3584, layers=28, heads=28, kv_heads=4, inter=18944, vocab=152064):
+    """Text decoder of transformers' Qwen2_5_VLForConditionalGeneration (the class models/vlm_tagger.py:163-184 instantiates), its
+    state-dict key names (transformers 5.x: model.language_model.*, lm_head.weight). Defaults = Qwen2.5-VL-7B-Instruct's geometry
+    (head_dim 128, q/k/v with bias, untied lm_head)."""
+    hd = hidden // heads
+    spec = [("model.language_model.embed_tokens.weight", (vocab, hidden), "emb1")]
+    for i in range(layers):
+        p = f"model.language_model.layers.{i}"
+        _linear(spec, p + ".self_attn.q_proj", heads * hd, hidden)
+        _linear(spec, p + ".self_attn.k_proj", kv_heads * hd, hidden)
+        _linear(spec, p + ".self_attn.v_proj", kv_heads * hd, hidden)
+        _linear(spec, p + ".self_attn.o_proj", hidden, heads * hd, bias=False)
+        _linear(spec, p + ".mlp.gate_proj", inter, hidden, bias=False)
+        _linear(spec, p + ".mlp.up_proj", inter, hidden, bias=False)
+        _linear(spec, p + ".mlp.down_proj", hidden, inter, bias=False)
+        spec.append((p + ".input_layernorm.weight", (hidden,), "ln_w"))
+        spec.append((p + ".post_attention_layernorm.weight", (hidden,), "ln_w"))
+    spec.append(("model.language_model.norm.weight", (hidden,), "ln_w"))
+    spec.append(("lm_head.weight", (vocab, hidden), "linear"))
+    return spec
+
+
+# the reduced-depth configuration of the VLM parity tests (tests/golden/make_vlm_golden.py): Qwen2.5-VL's head_dim 128 and 2:1 grouped
+# KV heads at a size the CPU oracle generates from in seconds
+VLM_TINY = dict(hidden=512, layers=4, heads=4, kv_heads=2, inter=1408, vocab=2048)
+
 SPECS = {
+    "qwen2_5_vl_text": qwen2_5_vl_text_spec,
+    "qwen2_5_vl_text_tiny": lambda: qwen2_5_vl_text_spec(**VLM_TINY),
     "topiq": topiq_spec,
     "resnet50": lambda: resnet_spec("semantic_model.", True, [3, 4, 6, 3]),
     "clip": clip_vit_spec,
@@ -269,6 +297,8 @@ def _draw(rng, shape, kind):
         return rng.standard_normal(shape, dtype=np.float32) * np.float32(0.1)
     if kind == "emb":
         return rng.standard_normal(shape, dtype=np.float32) * np.float32(0.02)
+    if kind == "emb1":      # token embeddings of a pre-norm decoder (RMSNorm rescales them; unit scale keeps bf16 away from its subnormals)
+        return rng.standard_normal(shape, dtype=np.float32)
     raise ValueError(kind)
 
 

@@ -42,7 +42,8 @@ enum fe_model {
   FE_MODEL_CLIP = 1,      /* open_clip ViT-L/14 image tower             (processing/scorer.py:508,662)     */
   FE_MODEL_SAMP = 2,      /* SAMPNet (ResNet-18 + pattern pooling)      (models/samp_net.py:665-791)       */
   FE_MODEL_U2NETP = 3,    /* U2-Net-P saliency                          (models/samp_net.py:258-342)       */
-  FE_MODEL_AESTHETIC = 4  /* Linear(768,256)-ReLU-Linear(256,1)         (processing/scorer.py:579-583)     */
+  FE_MODEL_AESTHETIC = 4, /* Linear(768,256)-ReLU-Linear(256,1)         (processing/scorer.py:579-583)     */
+  FE_MODEL_VLM = 5        /* Qwen2.5-VL text decoder (VLM tagger)       (models/vlm_tagger.py:163-184)     */
 };
 
 enum fe_act { FE_ACT_NONE = 0, FE_ACT_RELU = 1, FE_ACT_GELU = 2, FE_ACT_SIGMOID = 3, FE_ACT_SOFTPLUS = 5 /* torch.nn.Softplus(beta=1, threshold=20) */ };
@@ -72,6 +73,25 @@ int fe_set_microbatch(fe_ctx* ctx, int n);
 enum fe_precision { FE_PRECISION_F32 = 0, FE_PRECISION_BF16 = 1, FE_PRECISION_F16 = 2, FE_PRECISION_RES32 = 16 };
 int fe_set_precision(fe_ctx* ctx, int precision);
 int fe_model_precision(fe_ctx* ctx, int model); /* enum fe_precision value of a loaded model, with its RES32 bit; -1 when it is not loaded */
+
+/* ---- VLM tagger (BASELINE configs[4]), slice 1: the text decoder --------------------------------------------
+ * Reference: models/vlm_tagger.py loads transformers' Qwen2_5_VLForConditionalGeneration in bfloat16 (:155-184) and calls
+ * generate(**inputs, max_new_tokens=..., do_sample=False) (:250-259, :355-360). FE_MODEL_VLM takes that class's state dict (tensor
+ * names model.language_model.* and lm_head.weight; model.visual.* is ignored in this slice) and always runs in bf16, with the
+ * rounding points of the bf16 torch modules. Token ids in, token ids out: tokenizer, chat template and tag parsing stay on the host
+ * (facet_amd/vlm_tagger.py). fe_vlm_configure gives the geometry the tensor shapes do not determine (defaults = Qwen2.5-VL-7B:
+ * 28 heads, 4 KV heads, head_dim 128, rope_theta 1e6, rms eps 1e-6, mrope_section 16/24/24) and is read by the NEXT
+ * fe_weights_commit(FE_MODEL_VLM).
+ * fe_vlm_prefill: n_seq prompts of `len` tokens each (tokens [n_seq][len], position_ids [3][n_seq][len] = the temporal / height /
+ * width rotary positions transformers' get_rope_index yields; all three equal for text tokens) fill a fresh KV cache of max_seq
+ * positions per sequence (<= 8192) and return the greedy next token of every sequence (argmax of the bf16 logits, first index on
+ * ties, as torch.argmax) and, when `logits` is not NULL, those logits [n_seq][vocab]. fe_vlm_decode_step appends one token per
+ * sequence (tokens [n_seq], position_ids [3][n_seq]). dims: vocab, hidden, layers, heads, kv_heads, intermediate, max_seq, cur_len. */
+int fe_vlm_configure(fe_ctx* ctx, int n_heads, int n_kv_heads, int head_dim, float rope_theta, float rms_eps, const int* mrope_section);
+int fe_vlm_dims(fe_ctx* ctx, int* dims8);
+int fe_vlm_prefill(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int len, int max_seq, int32_t* next_tokens,
+                   float* logits);
+int fe_vlm_decode_step(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int32_t* next_tokens, float* logits);
 
 /* ---- device buffers (so callers can keep batches resident in HBM without torch) ------------- */
 int fe_dev_alloc(fe_ctx* ctx, size_t bytes, void** d_out);
