@@ -23,9 +23,11 @@ FE_FACE_FLOATS = 739
 FE_STATS_DOUBLES = 264
 FILTERS = {"lanczos": 1, "bilinear": 2, "bicubic": 3}
 FE_PRECISION_RES32 = 16      # or-ed onto a 2-byte precision: fp32 residual streams (include/facet_engine.h fe_precision)
+FE_PRECISION_SPLIT3 = 32     # or-ed onto f16: split-operand GEMMs of the CLIP tower ("f16x3")
 PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2, "half": 2,
-             "bf16+r32": 1 | FE_PRECISION_RES32, "f16+r32": 2 | FE_PRECISION_RES32}
-PRECISION_NAME = {0: "f32", 1: "bf16", 2: "f16", 1 | FE_PRECISION_RES32: "bf16+r32", 2 | FE_PRECISION_RES32: "f16+r32"}
+             "bf16+r32": 1 | FE_PRECISION_RES32, "f16+r32": 2 | FE_PRECISION_RES32, "f16x3": 2 | FE_PRECISION_RES32 | FE_PRECISION_SPLIT3}
+PRECISION_NAME = {0: "f32", 1: "bf16", 2: "f16", 1 | FE_PRECISION_RES32: "bf16+r32", 2 | FE_PRECISION_RES32: "f16+r32",
+                  2 | FE_PRECISION_RES32 | FE_PRECISION_SPLIT3: "f16x3"}
 ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "sigmoid": 3, "softplus": 5}
 
 

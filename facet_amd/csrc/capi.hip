@@ -298,17 +298,19 @@ int fe_weights_set(fe_ctx* ctx, int model, const char* name, const float* data, 
 }
 int fe_set_precision(fe_ctx* ctx, int precision) {
   FE_API_BEGIN(ctx)
-  const int base = precision & ~FE_PRECISION_RES32;
+  const int base = precision & ~(FE_PRECISION_RES32 | FE_PRECISION_SPLIT3);
+  FE_CHECK(!(precision & FE_PRECISION_SPLIT3) || base == FE_PRECISION_F16, "set_precision: FE_PRECISION_SPLIT3 qualifies FE_PRECISION_F16");
   FE_CHECK(base == FE_PRECISION_F32 || base == FE_PRECISION_BF16 || base == FE_PRECISION_F16, "set_precision: %d", precision);
   FE_CHECK(base != FE_PRECISION_F32 || !(precision & FE_PRECISION_RES32), "set_precision: FE_PRECISION_RES32 qualifies a 2-byte precision");
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   ctx->c.precision = base;
-  ctx->c.res32 = (precision & FE_PRECISION_RES32) != 0;
+  ctx->c.res32 = (precision & (FE_PRECISION_RES32 | FE_PRECISION_SPLIT3)) != 0;      // split operands imply fp32 streams
+  ctx->c.split3 = (precision & FE_PRECISION_SPLIT3) != 0;
   FE_API_END(ctx)
 }
 int fe_model_precision(fe_ctx* ctx, int model) {
   if (!ctx) return -1;
-  auto code = [](const DeviceWeights& dw) { return dw.prec | (dw.res32 ? FE_PRECISION_RES32 : 0); };
+  auto code = [](const DeviceWeights& dw) { return dw.prec | (dw.res32 ? FE_PRECISION_RES32 : 0) | (dw.split3 ? FE_PRECISION_SPLIT3 : 0); };
   if (model == FE_MODEL_TOPIQ && ctx->c.topiq) return code(ctx->c.topiq->dw);
   if (model == FE_MODEL_U2NETP && ctx->c.u2netp) return code(ctx->c.u2netp->dw);
   if (model == FE_MODEL_SAMP && ctx->c.samp) return code(ctx->c.samp->dw);
@@ -350,7 +352,7 @@ int fe_weights_commit(fe_ctx* ctx, int model) {
     ctx->c.u2netp = std::move(m);
   } else if (model == FE_MODEL_CLIP) {
     auto m = std::make_unique<ClipModel>();
-    m->dw.prec = ctx->c.precision; m->dw.res32 = ctx->c.res32;      // the image tower; the text tower (built below, run once per vocabulary) stays fp32
+    m->dw.prec = ctx->c.precision; m->dw.res32 = ctx->c.res32; m->dw.split3 = ctx->c.split3;      // the image tower; the text tower (built below, run once per vocabulary) stays fp32
     build_clip(*m, ws);
     ctx->c.clip = std::move(m);
     if (ws.has("token_embedding.weight")) {   // full CLIP checkpoint: also build the text tower
@@ -926,6 +928,7 @@ static int clip_tower_chunk(const ClipModel& m, int n) {
 }
 static void clip_tower(Ctx& C, const Tensor& x, float* feat) {   // in the precision the tower was committed under
   const bool r32 = C.clip->dw.res32;      // fp32 token stream around the 2-byte GEMMs
+  if (C.clip->split3) { clip_forward_split3(C, *C.clip, x, feat); return; }
   if (C.clip->dw.prec == PREC_BF16) { if (r32) clip_forward<bf16, float>(C, *C.clip, x, feat); else clip_forward<bf16>(C, *C.clip, x, feat); }
   else if (C.clip->dw.prec == PREC_F16) { if (r32) clip_forward<f16, float>(C, *C.clip, x, feat); else clip_forward<f16>(C, *C.clip, x, feat); }
   else clip_forward<float>(C, *C.clip, x, feat);

@@ -196,7 +196,7 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
           float x = acc[i][j][4 * g + e] * (hs ? sc[e] : 1.f) + sf[e];
           if (!p.res_after_act) x += rvi[e];
           if (ACTK == 1) x = x > 0.f ? x : 0.f;
-          else if (ACTK < 0) x = fe_apply_act_fast(x, p.act);
+          else if (ACTK < 0) x = p.exact_act ? fe_apply_act(x, p.act) : fe_apply_act_fast(x, p.act);
           if (p.res_after_act) x += rvi[e];
           v[e] = x;
           acc[i][j][4 * g + e] = x;          // kept for the fp32 pass below
@@ -443,12 +443,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
         l_cok = (cil + cofs) < p.Cin;
       }
     };
+    // a_wrap (GEMM form only): the A operand restarts from column 0 once, at slab a_wrap - the split-operand products
+    // [xh | xl | xh] . [Wh | Wh | Wl]^T read their activation row as [xh | xl] and wrap (ClipModel split3, model_clip.hip)
+    const int a_wrap = (ONE_TAP && p.a_wrap > 0) ? p.a_wrap : 0x3fffffff;
+    int ga3 = 0;                                          // slab of A being issued (== g3 until the wrap)
     auto lean_end = [&]() {
       if constexpr (!ONE_TAP) {
         advance(tap0, kh0, kw0, ci0);
         if (UNITS == 2) advance(tap1, kh1, kw1, ci1);
       }
       ++g3;
+      ga3 = g3 >= a_wrap ? g3 - a_wrap : g3;
     };
 #define FL_PIECE(SLOT, Q)                                                                                               \
     {                                                                                                                   \
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
       if constexpr ((Q) < AI) {                                                                                         \
         if constexpr (ONE_TAP) {                                                                                        \
           const unsigned off_ = live_ ? aoffs_l[(Q) < AI ? (Q) : 0] : 0xFFFFFFF0u;                      \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 1024 * NW * (Q)), 16, (int)off_, g3 * 64, 0, 0);   \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (h_lptr_t)(dA + (SLOT) * SLAB + 1024 * NW * (Q)), 16, (int)off_, ga3 * 64, 0, 0);  \
         } else {                                                                                                        \
           const bool ok_ = ((amask[(Q) < AI ? (Q) : 0] >> l_tap) & 1ull) && l_cok && live_;                              \
           const unsigned off_ = ok_ ? aoffs[(Q) < AI ? (Q) : 0] + (unsigned)l_tb : 0xFFFFFFF0u;                          \
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
             float x = v[e] * sc[e] + sf[e];
             if (hres && !p.res_after_act) x += rf[e];
             if constexpr (MODE == 2) x = x > 0.f ? x : x * sl[e];
-            else x = fe_apply_act_fast(x, p.act);
+            else x = (S32 && p.exact_act) ? fe_apply_act(x, p.act) : fe_apply_act_fast(x, p.act);
             if (hres && p.res_after_act) x += rf[e];
             if (p.gate) x *= p.gate_c1 ? gs[it] : gf[e];
             if (!cfull && colb + e >= p.Cout) x = 0.f;

@@ -29,6 +29,7 @@ class DeviceWeights {
  public:
   int prec = 0;   // Precision the owning model is built for: pack_conv also emits the 2-byte forms (bf16 / f16) when it is not PREC_F32
   bool res32 = false;   // FE_PRECISION_RES32: the model keeps its residual / skip streams in fp32 around 2-byte GEMM operands
+  bool split3 = false;  // FE_PRECISION_SPLIT3 (CLIP image tower only)
   bool half_only = false;   // 2-byte models whose every layer has a 2-byte form (the VLM decoder): no fp32 / Winograd / tap copies uploaded
   ~DeviceWeights() { release(); }
   float* upload(const std::vector<float>& v);
@@ -51,6 +52,7 @@ struct LayerNormW {
 // Precision of a model's activations / weights, chosen per context before fe_weights_commit (fe_set_precision).
 enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
 constexpr int PREC_RES32_FLAG = 16;   // or-ed into fe_set_precision's argument (include/facet_engine.h FE_PRECISION_RES32)
+constexpr int PREC_SPLIT3_FLAG = 32;  // FE_PRECISION_SPLIT3: split-operand fp16 GEMMs (the ViT tower; implies fp32 streams)
 template <class T> struct PrecOf { static constexpr int value = PREC_F32; };
 template <> struct PrecOf<bf16> { static constexpr int value = PREC_BF16; };
 template <> struct PrecOf<f16> { static constexpr int value = PREC_F16; };
@@ -209,6 +211,7 @@ struct Ctx {
   int force_variant = 0;   // developer hook: forwarded to ConvParams.variant
   int precision = PREC_F32;   // what the NEXT fe_weights_commit builds (fe_set_precision); each model remembers its own
   bool res32 = false;         // FE_PRECISION_RES32 of the next commit: fp32 residual streams around 2-byte GEMM operands
+  bool split3 = false;        // FE_PRECISION_SPLIT3 of the next commit
   // TOPIQ GatedConv activations picked up by the next fe_weights_commit(FE_MODEL_TOPIQ) (fe_topiq_configure)
   int topiq_gate_act = ACT_GELU, topiq_wblk_act = ACT_GELU;
 
@@ -276,7 +279,12 @@ void sampnet_forward(Ctx& c, const SampModel& m, const Tensor& x_nhwc4, const Te
                      float* dist);
 
 // ---- CLIP ViT image tower + aesthetic MLP -------------------------------------------------------------
-struct ClipBlockW { LayerNormW ln1, ln2; MHAW attn; ConvW fc, proj; };
+struct ClipBlockW {
+  LayerNormW ln1, ln2; MHAW attn; ConvW fc, proj;
+  // split-operand forms (ClipModel::split3): fused q|k|v and c_fc as [Wh | Wh | Wl] (K' = 3K, against activation rows [xh | xl] read
+  // with a wrap), out_proj as [Wh | Wl] (K' = 2K against the plain fp16 attention output read twice), c_proj as [Wh | Wh | Wl]
+  ConvW qkv3, out2, fc3, proj3;
+};
 struct ClipModel {
   DeviceWeights dw;   // dw.prec = the precision this model was committed under
   ConvW patch, proj;
@@ -284,6 +292,11 @@ struct ClipModel {
   LayerNormW ln_pre, ln_post;
   std::vector<ClipBlockW> blocks;
   int width = 0, heads = 0, tokens = 0, patch_size = 0, out_dim = 0;
+  // FE_PRECISION_F16 | FE_PRECISION_SPLIT3: every weight and every GEMM operand that LayerNorm or GELU produces is carried as an fp16
+  // pair hi + lo (hi = fp16(x), lo = fp16(x - hi): ~22 significant bits) and the products xh.Wh + xl.Wh + xh.Wl are accumulated in
+  // fp32 by ONE launch over the concatenated operands - three times the matrix work of plain fp16, fp32-class results
+  bool split3 = false;
+  float* zero_bias = nullptr;   // [width] zeros: the V bias rides in the fused projection's shift
 };
 struct AestheticModel { DeviceWeights dw; ConvW l0, l2; };
 // CLIP text tower (open_clip TextTransformer: causal, pooled at the EOT token) — SURVEY §8(f)-3
@@ -305,6 +318,7 @@ void build_aesthetic(AestheticModel& m, const WeightStore& ws);
 // input - T, or float under FE_PRECISION_RES32; input pixels and output features are fp32 either way
 template <class T, class RT = T>
 void clip_forward(Ctx& c, const ClipModel& m, const Tensor& x_nhwc4, float* feat);
+void clip_forward_split3(Ctx& c, const ClipModel& m, const Tensor& x_nhwc4, float* feat);      // split-operand fp16 tower (ClipModel::split3)
 void aesthetic_forward(Ctx& c, const AestheticModel& m, const float* feat, int B, float* raw);
 void l2_normalize(Ctx& c, const float* x, float* y, int rows, int d);
 

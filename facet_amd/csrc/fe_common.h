@@ -239,6 +239,8 @@ struct ConvParamsT {
   const float* res32; int ldr32;
   float* y32; int ldy32;
   unsigned r32_span, y32_span;      // set by launch_conv_bf16: byte spans for buffer addressing
+  int a_wrap;                       // 2-byte GEMM form: > 0 = the A row holds only a_wrap * 32 columns and is read again from column 0 after them
+  int exact_act;                    // 2-byte fp32-stream forms: erf GELU instead of the tanh form (results that are NOT rounded to 2 bytes)
 };
 using ConvParams = ConvParamsT<float>;
 using ConvParamsH = ConvParamsT<bf16>;
@@ -374,6 +376,10 @@ void launch_gemm_skinny(const TI* x, int ldx, const TW* w, int ldw, const float*
 void launch_sigmoid(const Tensor& x, const Tensor& y, hipStream_t s);
 void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s);
 // LayerNorm over last dim of a [rows][d] matrix (eps inside sqrt, biased variance); statistics in fp32
+// LayerNorm of fp32 rows written as fp16 pairs: y[row] = [hi(d) | lo(d)], hi = fp16(v), lo = fp16(v - hi) (ldy >= 2 d); d = 1024 or 768
+void launch_layernorm_split(const float* x, int ldx, f16* y, int ldy, const float* g, const float* b, int rows, int d, float eps, hipStream_t s);
+// x fp32 [rows][cols] -> y fp16 [rows][2 cols] = [hi | lo]
+void launch_split_hi_lo(const float* x, f16* y, size_t rows, int cols, hipStream_t s);
 template <class T, class TO>   // TO = T, or a 2-byte TO behind fp32 rows (the fp32 residual stream of the reduced-precision path)
 void launch_layernorm(const T* x, int ldx, TO* y, int ldy, const float* g, const float* b,
                       int rows, int d, float eps, hipStream_t s);

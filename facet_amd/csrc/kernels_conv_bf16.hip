@@ -62,7 +62,10 @@ static void launch_bf16_tile(const ConvParamsE& p, int tile, bool one_tap, hipSt
 
 void launch_conv_bf16(const ConvParamsE& p0, hipStream_t s) {
   ConvParamsE p = p0;
-  FE_CHECK(p.x && p.w && (p.y || p.y32) && (!p.y || p.ldy >= p.Cout) && p.ldx >= p.Cin, "conv_bf16: null operand or row stride below the channel count");
+  const int acols = p.a_wrap > 0 ? p.a_wrap * 32 : p.Cin;      // columns an A row really holds (split-operand GEMMs wrap: fe_common.h a_wrap)
+  FE_CHECK(p.x && p.w && (p.y || p.y32) && (!p.y || p.ldy >= p.Cout) && p.ldx >= acols, "conv_bf16: null operand or row stride below the channel count");
+  FE_CHECK(p.a_wrap <= 0 || (p.KH * p.KW == 1 && p.Cin % 64 == 0 && p.Kp == p.Cin && p.a_wrap * 32 < p.Cin && p.Cin <= 2 * p.a_wrap * 32),
+           "conv_bf16: a_wrap needs the GEMM form (1x1, K %% 64 == 0) and K <= twice the wrapped width");
   const bool f32s = p.y32 || p.res32;      // fp32 residual / output streams (FE_PRECISION_RES32 models)
   FE_CHECK(!f32s || ((!p.y32 || p.ldy32 >= p.Cout) && (!p.res32 || p.ldr32 >= p.Cout) && !p.res && !p.pad_store && p.batch <= 1 && p.act != ACT_PRELU),
            "conv_bf16: fp32 streams take no 2-byte residual / pad_store / batched launch / PReLU");
@@ -81,7 +84,7 @@ void launch_conv_bf16(const ConvParamsE& p0, hipStream_t s) {
   FE_CHECK(ntaps == 1 || p.Cin % p.cb == 0, "conv_bf16: spatial kernels need Cin %% %d == 0 (Cin=%d)", p.cb, p.Cin);
   FE_CHECK(p.batch == 1 || (!p.res && !p.gate && !p.scale), "conv_bf16: batched launches take no res/gate/scale");
   FE_CHECK((long long)p.N * p.H * p.W < (1ll << 31), "conv_bf16: too many input pixels");
-  const unsigned long long xs = ((unsigned long long)p.N * p.H * p.W - 1) * (unsigned long long)p.ldx * 2 + (unsigned long long)p.Cin * 2;
+  const unsigned long long xs = ((unsigned long long)p.N * p.H * p.W - 1) * (unsigned long long)p.ldx * 2 + (unsigned long long)acols * 2;
   const unsigned long long ws = ((unsigned long long)p.Cout - 1) * (unsigned long long)p.ldw * 2 + (unsigned long long)p.Kp * 2;
   {      // tensors past 4 GiB (input, or the output / residual the wide tiles address through buffers): image groups that fit
     unsigned long long ysp = (unsigned long long)p.M * (unsigned long long)(p.ldy > p.ldr ? p.ldy : p.ldr) * 2;

@@ -525,6 +525,71 @@ void launch_layernorm(const T* x, int ldx, TO* y, int ldy, const float* g, const
   FE_HIP(hipGetLastError());
 }
 
+// LayerNorm of an fp32 row written as an fp16 pair per element (split-operand GEMMs, ClipModel::split3): one wave per row, the row in
+// registers (d = 256 * NV), statistics in fp32 as layernorm_reg_kernel
+template <int NV>
+__global__ void layernorm_split_kernel(const float* __restrict__ x, int ldx, f16* __restrict__ y, int ldy, const float* __restrict__ g, const float* __restrict__ b,
+                                       int rows, float eps) {
+  constexpr int d = 256 * NV;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int row = wave; row < rows; row += nwaves) {
+    const float* xr = x + (size_t)row * ldx;
+    float4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { v[k] = *reinterpret_cast<const float4*>(xr + 256 * k + 4 * lane); sum += (v[k].x + v[k].y) + (v[k].z + v[k].w); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)d;
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+      var += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)d + eps);
+    f16* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const float4 gv = *reinterpret_cast<const float4*>(g + 256 * k + 4 * lane), bv = *reinterpret_cast<const float4*>(b + 256 * k + 4 * lane);
+      const float4 o = make_float4(v[k].x * rstd * gv.x + bv.x, v[k].y * rstd * gv.y + bv.y, v[k].z * rstd * gv.z + bv.z, v[k].w * rstd * gv.w + bv.w);
+      const float4 hi = make_float4((float)fe_to_f16(o.x), (float)fe_to_f16(o.y), (float)fe_to_f16(o.z), (float)fe_to_f16(o.w));
+      st4(yr + 256 * k + 4 * lane, hi);
+      st4(yr + d + 256 * k + 4 * lane, make_float4(o.x - hi.x, o.y - hi.y, o.z - hi.z, o.w - hi.w));
+    }
+  }
+}
+void launch_layernorm_split(const float* x, int ldx, f16* y, int ldy, const float* g, const float* b, int rows, int d, float eps, hipStream_t s) {
+  FE_CHECK((d == 1024 || d == 768 || d == 512 || d == 256) && ldx % 4 == 0 && ldy % 4 == 0 && ldy >= 2 * d && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
+           (((uintptr_t)g | (uintptr_t)b) & 15) == 0, "layernorm_split: d = %d / strides / alignment", d);
+  const int blocks = grid_for((size_t)rows * 64);
+  if (d == 1024) hipLaunchKernelGGL((layernorm_split_kernel<4>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  else if (d == 768) hipLaunchKernelGGL((layernorm_split_kernel<3>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  else if (d == 512) hipLaunchKernelGGL((layernorm_split_kernel<2>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  else hipLaunchKernelGGL((layernorm_split_kernel<1>), dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, g, b, rows, eps);
+  FE_HIP(hipGetLastError());
+}
+__global__ void split_hi_lo_kernel(const float* __restrict__ x, f16* __restrict__ y, size_t rows, int cols) {
+  const size_t total = rows * (size_t)(cols / 4);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / (cols / 4);
+    const int c = (int)(i - row * (cols / 4)) * 4;
+    const float4 o = *reinterpret_cast<const float4*>(x + row * cols + c);
+    const float4 hi = make_float4((float)fe_to_f16(o.x), (float)fe_to_f16(o.y), (float)fe_to_f16(o.z), (float)fe_to_f16(o.w));
+    f16* yr = y + row * 2 * cols;
+    st4(yr + c, hi);
+    st4(yr + cols + c, make_float4(o.x - hi.x, o.y - hi.y, o.z - hi.z, o.w - hi.w));
+  }
+}
+void launch_split_hi_lo(const float* x, f16* y, size_t rows, int cols, hipStream_t s) {
+  FE_CHECK(cols % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0, "split_hi_lo: alignment");
+  hipLaunchKernelGGL(split_hi_lo_kernel, dim3(grid_for(rows * (size_t)(cols / 4))), dim3(256), 0, s, x, y, rows, cols);
+  FE_HIP(hipGetLastError());
+}
+
 // ---- row softmax, one wave per row ---------------------------------------------------------------------
 __global__ void softmax_rows_kernel(float* __restrict__ x, int ld, int rows, int d) {
   const int lane = threadIdx.x & 63;

@@ -7,12 +7,49 @@
 // 24 x { x += MHA(ln_1(x)); x += c_proj(GELU(c_fc(ln_2(x)))) } -> ln_post(x[:,0]) @ proj. Exact-erf GELU, LN eps 1e-5.
 // Parity is checked against oracle/clip_vit.py (same restatement in torch-CPU): "parity unpinned".
 #include "engine.h"
+#include <algorithm>
 #include <cmath>
 
 namespace fe {
 
+// Split-operand weight of a linear layer W [N][K] (+ bias): rows [Wh | Wh | Wl] (terms = 3) or [Wh | Wl] (terms = 2) in fp16, where
+// Wh = fp16(2^s W), Wl = fp16(2^s W - Wh). The power of two keeps Wl out of fp16's subnormal range (weights ~ 1/sqrt(K)); it is undone
+// by the epilogue scale, which also carries `col_scale` (the 1/sqrt(head_dim) of the q rows). Consumed by gemm_split below.
+static ConvW pack_split(DeviceWeights& dw, int N, int K, const float* W, const float* bias, int terms, const std::vector<float>* col_scale = nullptr) {
+  FE_CHECK(K % 64 == 0 && (terms == 2 || terms == 3), "pack_split: K = %d", K);
+  float amax = 0.f;
+  for (size_t i = 0; i < (size_t)N * K; ++i) amax = std::max(amax, std::fabs(W[i]));
+  int s = 8;
+  while (s > 0 && amax * std::ldexp(1.0f, s) > 16384.f) --s;
+  const float up = std::ldexp(1.0f, s);
+  ConvW c;
+  c.Cout = N; c.Cin = K; c.KH = c.KW = 1; c.CinPad = K; c.K = K; c.Kp = K;
+  c.CinPadH = terms * K; c.KpH = terms * K; c.cb = 32; c.hprec = PREC_F16;
+  std::vector<uint16_t> packed((size_t)N * terms * K);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) {
+      const float w = W[(size_t)n * K + k] * up;
+      const uint16_t hb = f32_to_f16_bits(w);
+      // the fp16 value back as float (exact): sign, exponent, mantissa
+      const int e = (hb >> 10) & 31, mant = hb & 1023;
+      const float hf = (hb & 0x8000 ? -1.f : 1.f) * (e == 0 ? std::ldexp((float)mant, -24) : std::ldexp((float)(mant | 1024), e - 25));
+      const uint16_t lb = f32_to_f16_bits(w - hf);
+      uint16_t* row = &packed[(size_t)n * terms * K];
+      row[k] = hb;
+      if (terms == 3) { row[K + k] = hb; row[2 * K + k] = lb; }
+      else row[K + k] = lb;
+    }
+  c.wh = dw.upload_raw(packed.data(), packed.size() * sizeof(uint16_t));
+  std::vector<float> sc(N, 1.0f / up);
+  if (col_scale) for (int n = 0; n < N; ++n) sc[n] *= (*col_scale)[n];
+  c.scale = dw.upload(sc);
+  if (bias) { std::vector<float> bv(bias, bias + N); if (col_scale) for (int n = 0; n < N; ++n) bv[n] *= (*col_scale)[n]; c.shift = dw.upload(bv); }
+  return c;
+}
+
 void build_clip(ClipModel& m, const WeightStore& ws) {
   const std::string p = "visual.";
+  m.split3 = m.dw.split3 && m.dw.prec == PREC_F16;
   m.patch = build_conv(m.dw, ws, p + "conv1", "", false);
   m.width = m.patch.Cout;
   m.patch_size = m.patch.KH;
@@ -34,9 +71,23 @@ void build_clip(ClipModel& m, const WeightStore& ws) {
     w.attn = build_mha(m.dw, ws, b + ".attn", m.heads);
     w.fc = build_linear(m.dw, ws, b + ".mlp.c_fc", true);
     w.proj = build_linear(m.dw, ws, b + ".mlp.c_proj", true);
+    if (m.split3) {
+      const int d = m.width;
+      const HostTensor& Wi = ws.get(b + ".attn.in_proj_weight");
+      const HostTensor& Bi = ws.get(b + ".attn.in_proj_bias");
+      std::vector<float> cs(3 * d, 1.0f);      // q = (x Wq^T + bq) / sqrt(head_dim): scaled after the bias, like build_mha
+      for (int i = 0; i < d; ++i) cs[i] = 1.0f / std::sqrt((float)(d / m.heads));
+      w.qkv3 = pack_split(m.dw, 3 * d, d, Wi.data.data(), Bi.data.data(), 3, &cs);
+      w.out2 = pack_split(m.dw, d, d, ws.get(b + ".attn.out_proj.weight").data.data(), ws.get(b + ".attn.out_proj.bias").data.data(), 2);
+      const HostTensor& Wf = ws.get(b + ".mlp.c_fc.weight");
+      w.fc3 = pack_split(m.dw, (int)Wf.shape[0], d, Wf.data.data(), ws.get(b + ".mlp.c_fc.bias").data.data(), 3);
+      const HostTensor& Wp = ws.get(b + ".mlp.c_proj.weight");
+      w.proj3 = pack_split(m.dw, d, (int)Wp.shape[1], Wp.data.data(), ws.get(b + ".mlp.c_proj.bias").data.data(), 3);
+    }
     m.blocks.push_back(w);
   }
   FE_CHECK(!m.blocks.empty(), "clip: no transformer blocks found");
+  if (m.split3) m.zero_bias = m.dw.upload(std::vector<float>((size_t)m.width, 0.f));
   // proj is [width][out]: features = pooled @ proj  ==  Linear with weight proj^T
   const HostTensor& pr = ws.get(p + "proj");
   HostTensor prt;
@@ -212,6 +263,88 @@ template void clip_forward<bf16, bf16>(Ctx&, const ClipModel&, const Tensor&, fl
 template void clip_forward<f16, f16>(Ctx&, const ClipModel&, const Tensor&, float*);
 template void clip_forward<bf16, float>(Ctx&, const ClipModel&, const Tensor&, float*);
 template void clip_forward<f16, float>(Ctx&, const ClipModel&, const Tensor&, float*);
+
+// ---- split-operand fp16 tower (FE_PRECISION_F16 | FE_PRECISION_SPLIT3) ----------------------------------------------------------------
+// y = act(A . W3^T * scale + shift) (+ res32): A = fp16 rows holding a_cols columns ([xh | xl], or the plain x), W3 = pack_split's rows
+// of K' = w.KpH columns; the kernel reads A's columns 0 .. a_cols-1 and then, wrapped, 0 .. K' - a_cols - 1. Output: fp16 rows (y16) or
+// fp32 rows (y32, with an optional fp32 residual): the fp32-stream form of the kernel.
+static void gemm_split(Ctx& c, const ConvW& w, const f16* a, int lda, int a_cols, int M, f16* y16, int ldy16, float* y32, int ldy32, const float* res32, int ldr32,
+                       int act) {
+  ConvParamsT<f16> p{};
+  p.x = a; p.ldx = lda; p.w = (const f16*)w.wh; p.ldw = w.KpH; p.scale = w.scale; p.shift = w.shift;
+  p.y = y16; p.ldy = ldy16; p.y32 = y32; p.ldy32 = ldy32; p.res32 = res32; p.ldr32 = ldr32;
+  p.N = 1; p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.M = M; p.Cin = w.KpH; p.Cout = w.Cout;
+  p.KH = p.KW = 1; p.sh = p.sw = p.dh = p.dw = 1; p.K = w.KpH; p.Kp = w.KpH; p.cb = 32;
+  p.act = act; p.a_wrap = a_cols / 32; p.exact_act = 1;
+  FE_CHECK(a_cols % 64 == 0 && a_cols < w.KpH, "gemm_split: operand widths");
+  launch_conv_bf16(p, c.stream);
+  // algorithmic = the layer's 2 M K N; executed = the two or three operand products the matrix cores really ran (flops_saved < 0)
+  const double alg = 2.0 * M * (double)w.K * w.Cout, exec = 2.0 * M * (double)w.KpH * w.Cout;
+  c.flops_accum += alg; c.flops_saved -= exec - alg; c.flops_half += exec;
+}
+
+// vt[b][c][t] = qkv[b*T + t][2d + c] for t < T, 0 for T <= t < Lp   (V of the fused projection, transposed for the attention kernel)
+__global__ void clip_v_transpose_kernel(const f16* __restrict__ qkv, int ld, f16* __restrict__ vt, int B, int T, int Lp, int d) {
+  __shared__ f16 tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows per pass
+  for (int r = ty; r < 32; r += 8) {
+    const int t = t0 + r;
+    tile[r][tx] = t < T ? qkv[((size_t)b * T + t) * ld + 2 * d + c0 + tx] : (f16)0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int t = t0 + tx;
+    if (t < Lp) vt[((size_t)b * d + c0 + r) * Lp + t] = tile[tx][r];
+  }
+}
+
+void clip_forward_split3(Ctx& c, const ClipModel& m, const Tensor& x, float* feat) {
+  FE_CHECK(m.split3, "clip: the tower was not committed under FE_PRECISION_SPLIT3");
+  const size_t mark = c.arena.mark();
+  const int B = x.n, d = m.width, Tk = m.tokens, P = m.patch_size, H = m.heads;
+  const int gh = x.h / P, gw = x.w / P, rows = B * Tk, Lp = (Tk + 31) / 32 * 32, ff = m.blocks[0].fc3.Cout;
+  FE_CHECK(gh * gw + 1 == Tk && d % 64 == 0 && d / H == 64, "clip(split3): geometry");
+  float* tok = c.arena.array<float>((size_t)rows * d);
+  {  // patch embed (fp32 kernel, as in every precision)
+    ConvParams p{};
+    p.x = x.p; p.ldx = x.ld; p.w = m.patch.w; p.y = tok + d; p.ldy = d;
+    p.N = 1; p.H = x.h; p.W = x.w; p.Cin = m.patch.CinPad; p.Ho = gh; p.Wo = gw; p.Cout = d;
+    p.KH = p.KW = P; p.sh = p.sw = P; p.dh = p.dw = 1;
+    p.K = m.patch.K; p.Kp = m.patch.Kp; p.M = gh * gw;
+    p.batch = B; p.nb1 = 1; p.xs2 = (long long)x.h * x.w * x.ld; p.ys2 = (long long)Tk * d;
+    launch_conv(p, c.stream);
+    c.flops_accum += 2.0 * B * p.M * (double)(P * P * m.patch.Cin) * d;
+  }
+  hipLaunchKernelGGL(clip_embed_kernel<float>, dim3(2048), dim3(256), 0, c.stream, (const float*)tok, tok, m.cls, m.pos, B, Tk, d);
+  FE_HIP(hipGetLastError());
+  float* xa = c.arena.array<float>((size_t)rows * d);
+  f16* nb = c.arena.array<f16>((size_t)rows * 2 * d);          // LayerNorm output as [hi | lo]
+  f16* qkv = c.arena.array<f16>((size_t)rows * 3 * d);
+  f16* vt = c.arena.array<f16>((size_t)B * d * Lp);
+  f16* ao = c.arena.array<f16>((size_t)rows * d);
+  float* h32 = c.arena.array<float>((size_t)rows * ff);
+  f16* hb = c.arena.array<f16>((size_t)rows * 2 * ff);
+  launch_layernorm(tok, d, xa, d, m.ln_pre.g, m.ln_pre.b, rows, d, m.ln_pre.eps, c.stream);
+  float* cur = xa;
+  float* other = tok;
+  for (const ClipBlockW& w : m.blocks) {
+    launch_layernorm_split(cur, d, nb, 2 * d, w.ln1.g, w.ln1.b, rows, d, w.ln1.eps, c.stream);
+    gemm_split(c, w.qkv3, nb, 2 * d, 2 * d, rows, qkv, 3 * d, nullptr, 0, nullptr, 0, ACT_NONE);          // q (pre-scaled) | k | v, biases included
+    hipLaunchKernelGGL(clip_v_transpose_kernel, dim3(Lp / 32, d / 32, B), dim3(256), 0, c.stream, (const f16*)qkv, 3 * d, vt, B, Tk, Lp, d);
+    launch_attention((const f16*)qkv, 3 * d, (const f16*)(qkv + d), 3 * d, (const f16*)vt, Lp, m.zero_bias, ao, d, B, H, Tk, Tk, d, 0, c.stream);
+    c.flops_accum += 4.0 * B * H * (double)Tk * Tk * 64; c.flops_half += 4.0 * B * H * (double)Tk * Tk * 64;
+    gemm_split(c, w.out2, ao, d, d, rows, nullptr, 0, other, d, cur, d, ACT_NONE);                          // other = cur + out_proj(attn)
+    launch_layernorm_split(other, d, nb, 2 * d, w.ln2.g, w.ln2.b, rows, d, w.ln2.eps, c.stream);
+    gemm_split(c, w.fc3, nb, 2 * d, 2 * d, rows, nullptr, 0, h32, ff, nullptr, 0, ACT_GELU);                // erf GELU, fp32 out
+    launch_split_hi_lo(h32, hb, (size_t)rows, ff, c.stream);
+    gemm_split(c, w.proj3, hb, 2 * ff, 2 * ff, rows, nullptr, 0, cur, d, other, d, ACT_NONE);               // cur = other + c_proj(h)
+  }
+  float* pooled = c.arena.array<float>((size_t)B * d);
+  launch_layernorm(cur, Tk * d, pooled, d, m.ln_post.g, m.ln_post.b, B, d, m.ln_post.eps, c.stream);
+  linear_forward_xf32(c, m.proj, PREC_F16, (const float*)pooled, d, B, feat, m.out_dim, ACT_NONE);      // fp32 rows on the fp16 projection weights
+  c.arena.rewind(mark);
+}
 
 // raw[b] = Linear(256,1)(relu(Linear(768,256)(feat[b])))   (reference scorer.py:579-583; (x+1)*5 clamp stays on host)
 void aesthetic_forward(Ctx& c, const AestheticModel& m, const float* feat, int B, float* raw) {

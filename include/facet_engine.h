@@ -69,8 +69,12 @@ int fe_set_microbatch(fe_ctx* ctx, int n);
  *                      fp16's 11, fp32's exponent range).
  *   | FE_PRECISION_RES32  (or-ed onto a 2-byte precision) the residual / skip streams of the network (the ViT token stream, the ResNet
  *                      skip path) and the inputs of every LayerNorm stay fp32; only the GEMM operands are 2 bytes.
+ *   | FE_PRECISION_SPLIT3 (or-ed onto FE_PRECISION_F16; the CLIP image tower; implies RES32) split-operand fp16: every weight and every
+ *                      GEMM operand LayerNorm / GELU produce is an fp16 pair hi + lo (~22 significant bits) and one launch over the
+ *                      concatenated operands accumulates xh.Wh + xl.Wh + xh.Wl in fp32 - three times the matrix work of plain
+ *                      fp16 (still a fraction of fp32's), results that hold the fp32 path's 1e-3 gate on the final scores.
  * CLIP's 14x14 patch embedding and the non-7x7 three-channel first layers stay on the fp32 kernels in every precision. */
-enum fe_precision { FE_PRECISION_F32 = 0, FE_PRECISION_BF16 = 1, FE_PRECISION_F16 = 2, FE_PRECISION_RES32 = 16 };
+enum fe_precision { FE_PRECISION_F32 = 0, FE_PRECISION_BF16 = 1, FE_PRECISION_F16 = 2, FE_PRECISION_RES32 = 16, FE_PRECISION_SPLIT3 = 32 };
 int fe_set_precision(fe_ctx* ctx, int precision);
 int fe_model_precision(fe_ctx* ctx, int model); /* enum fe_precision value of a loaded model, with its RES32 bit; -1 when it is not loaded */
 

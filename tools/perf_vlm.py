@@ -1,0 +1,53 @@
+"""Throughput of the VLM tagger's text decoder at Qwen2.5-VL-7B's geometry (BASELINE configs[4] shape; slice 1 = decoder only).
+
+  python tools/perf_vlm.py [--layers 28] [--prompt 512] [--new 32] [--batches 1,8,32]
+
+Seeded synthetic weights in the 7B geometry (hidden 3584, 28 q heads over 4 KV heads of 128, intermediate 18944, vocab 152064); with
+--layers < 28 the per-layer work is measured on that many layers and the lm_head once, and both the measured and the 28-layer
+extrapolation are printed. Prefill is matrix-core bound (2 * parameters * tokens FLOPs); decode is HBM bound (every weight byte once per
+step, whatever the batch) - the decode line reports GB/s of weight traffic against the 8 TB/s peak.
+"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from facet_amd import Engine
+from facet_amd._lib import FE_MODEL_VLM
+from facet_amd.weights import synthetic_state_dict, qwen2_5_vl_text_spec
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--layers", type=int, default=8)
+ap.add_argument("--prompt", type=int, default=512)
+ap.add_argument("--new", type=int, default=16)
+ap.add_argument("--batches", default="1,8,32")
+a = ap.parse_args()
+H, NH, NKV, INTER, V = 3584, 28, 4, 18944, 152064
+t0 = time.time()
+sd = synthetic_state_dict(None, 3, spec=qwen2_5_vl_text_spec(hidden=H, layers=a.layers, heads=NH, kv_heads=NKV, inter=INTER, vocab=V))
+print(f"weights drawn in {time.time() - t0:.0f} s", flush=True)
+e = Engine(0, arena_bytes=40 << 30)
+e.vlm_configure(NH, NKV, 128, 1e6, 1e-6, (16, 24, 24))
+t0 = time.time()
+e.load_weights(FE_MODEL_VLM, sd)
+del sd
+print(f"committed in {time.time() - t0:.0f} s", flush=True)
+layer_params = H * (NH + 2 * NKV) * 128 + NH * 128 * H + 3 * H * INTER
+head_params = V * H
+for B in [int(b) for b in a.batches.split(",")]:
+    L = a.prompt
+    p = np.random.default_rng(B).integers(0, V, (B, L)).astype(np.int32)
+    e.vlm_prefill(p, max_seq=L + a.new + 8)
+    e.timer_start(); nxt = e.vlm_prefill(p, max_seq=L + a.new + 8); t_pre = e.timer_stop()
+    pos = np.full((3, B), L, np.int32)
+    e.vlm_decode_step(nxt, pos)
+    t0 = time.perf_counter()
+    for s in range(a.new):
+        nxt = e.vlm_decode_step(nxt, pos + 1 + s)
+    t_dec = (time.perf_counter() - t0) / a.new * 1e3
+    fl_pre = 2.0 * (a.layers * layer_params) * B * L + 2.0 * head_params * B + 4.0 * B * NH * L * (L + 1) / 2 * 128 * a.layers
+    wbytes = 2.0 * (a.layers * layer_params + head_params)
+    full_pre = t_pre * 28 / a.layers
+    full_dec = (t_dec - 0) * (28 * layer_params + head_params) / (a.layers * layer_params + head_params)
+    print(f"B={B:3d} L={L}: prefill {t_pre:8.2f} ms = {B * L / t_pre * 1e3:9.0f} tok/s, {fl_pre / t_pre / 1e9:7.1f} TFLOP/s ({a.layers} layers; x28/{a.layers}: {full_pre:.1f} ms) | "
+          f"decode {t_dec:6.3f} ms/step = {B / t_dec * 1e3:7.0f} tok/s, weights {wbytes / t_dec / 1e6:6.0f} GB/s = {wbytes / t_dec / 1e6 / 8000:.2f} of HBM peak "
+          f"(28 layers: ~{full_dec:.2f} ms/step)", flush=True)
+e.close()

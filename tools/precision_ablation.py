@@ -25,7 +25,7 @@ from facet_amd._lib import FE_MODEL_TOPIQ, FE_MODEL_CLIP, FE_MODEL_AESTHETIC, FE
 from facet_amd.weights import synthetic_state_dict, synthetic_images
 
 IDS = {"topiq": FE_MODEL_TOPIQ, "clip": FE_MODEL_CLIP, "aesthetic": FE_MODEL_AESTHETIC, "u2netp": FE_MODEL_U2NETP, "samp_net": FE_MODEL_SAMP}
-POLICIES = ["f32", "bf16", "f16", "bf16+r32", "f16+r32"]
+POLICIES = ["f32", "bf16", "f16", "bf16+r32", "f16+r32", "f16x3"]
 
 
 def comp_score(dist):
@@ -168,7 +168,8 @@ def main():
         except Exception as ex:      # a policy this build does not have: say so and go on
             print(f"[{group} {name}] not run: {ex}", flush=True)
     for pol in pols:
-        attempt("topiq", pol, lambda: run_topiq(pol, topiq_sets))
+        if pol != "f16x3":      # split operands exist for the ViT tower only
+            attempt("topiq", pol, lambda: run_topiq(pol, topiq_sets))
         attempt("clip", pol, lambda: run_clip(pol, clip_x))
     for pu, ps in SAMP_POLICIES:
         if pu.split("+")[0] in [p.split("+")[0] for p in pols] or pu == "f32":
