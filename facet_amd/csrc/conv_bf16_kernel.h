@@ -157,6 +157,8 @@ __device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const C
 // follows). Same register layout and LDS staging as h_epilogue_wide: the 2-byte image of the whole wave tile first, then the fp32
 // values one 32-column block at a time through the same wave-private region (144 bytes per row either way), 16-byte stores, eight
 // lanes per 128-byte row segment. ACTK: 0 none, 1 ReLU, -1 named by p.act. No gate, no pad_store.
+// OUT == 3: the split-pair output of the split-operand GEMMs (ClipModel::split3) - no fp32 rows; the result leaves as two 2-byte
+// values per element, hi = round(v) at column c and lo = round(v - hi) at column p.split_lo_off + c of the same row of p.y.
 template <class E, int TM, int TN, int ACTK, int OUT>
 __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const ConvParamsT<E>& p, const int row0, const int col0,
                                                   const int lane, char* const stage) {
@@ -199,9 +201,9 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
           else if (ACTK < 0) x = p.exact_act ? fe_apply_act(x, p.act) : fe_apply_act_fast(x, p.act);
           if (p.res_after_act) x += rvi[e];
           v[e] = x;
-          acc[i][j][4 * g + e] = x;          // kept for the fp32 pass below
+          acc[i][j][4 * g + e] = OUT == 3 ? x - (float)(E)x : x;          // kept for the second pass below (OUT == 3: the low part)
         }
-        if (OUT == 2) {
+        if (OUT >= 2) {
           h_v2u o;
           o.x = fe_pack2((const E*)nullptr, v[0], v[1]); o.y = fe_pack2((const E*)nullptr, v[2], v[3]);
           *reinterpret_cast<h_v2u*>(stage + (32 * i + r) * PITCH + (32 * j + 8 * g + 4 * h) * 2) = o;
@@ -212,7 +214,7 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (OUT == 2) {
+  auto store_e_image = [&](const unsigned col_off_bytes) __attribute__((always_inline)) {      // the staged 2-byte image of the wave tile -> 16-byte row stores
     constexpr int LPR = TN * 4, RPI = 64 / LPR;
     const int lr = lane / LPR, lc = lane % LPR;
     const int c = col0 + lc * 8;
@@ -220,9 +222,26 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
     for (int it = 0; it < TM * 32 / RPI; ++it) {
       const int row = it * RPI + lr, m = row0 + row;
       const h_v4 d = *reinterpret_cast<const h_v4*>(stage + row * PITCH + lc * 16);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h_v4u, d), ry, (int)((m < p.M && c < p.Cout) ? (unsigned)m * (unsigned)(p.ldy * 2) + (unsigned)c * 2u : OOB), 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h_v4u, d), ry, (int)((m < p.M && c < p.Cout) ? (unsigned)m * (unsigned)(p.ldy * 2) + (unsigned)c * 2u + col_off_bytes : OOB), 0, 0);
       if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  if (OUT >= 2) store_e_image(0u);
+  if (OUT == 3) {      // second image: the low parts, at column split_lo_off
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          h_v2u o;
+          o.x = fe_pack2((const E*)nullptr, acc[i][j][4 * g], acc[i][j][4 * g + 1]); o.y = fe_pack2((const E*)nullptr, acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          *reinterpret_cast<h_v2u*>(stage + (32 * i + r) * PITCH + (32 * j + 8 * g + 4 * h) * 2) = o;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    store_e_image((unsigned)p.split_lo_off * 2u);
+    return;
   }
   // fp32 rows: one 32-column block of the wave tile at a time through the same staging region
   const int lr = lane >> 3, lc = lane & 7;
@@ -388,7 +407,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
       // form that reads activation, gate and residual order from the parameters
       const bool plain = !p.gate && !(p.res && p.res_after_act);
       if constexpr (S32) {      // fp32-stream forms (launch_conv_bf16 admits them only without gate / E-typed residual / pad_store)
-        if (!p.y && p.act == ACT_NONE && !p.res_after_act) h_epilogue_wide32<E, TM, TN, 0, 1>(acc, p, row0, col0, lane, stage);        // ViT projections
+        if (p.split_lo_off > 0) h_epilogue_wide32<E, TM, TN, -1, 3>(acc, p, row0, col0, lane, stage);                                  // split-pair output
+        else if (!p.y && p.act == ACT_NONE && !p.res_after_act) h_epilogue_wide32<E, TM, TN, 0, 1>(acc, p, row0, col0, lane, stage);        // ViT projections
         else if (p.y && p.act == ACT_RELU && !p.res_after_act) h_epilogue_wide32<E, TM, TN, 1, 2>(acc, p, row0, col0, lane, stage);    // ResNet block outputs
         else h_epilogue_wide32<E, TM, TN, -1, 2>(acc, p, row0, col0, lane, stage);      // anything else (a null p.y is an empty buffer: stores dropped)
         return;
@@ -681,6 +701,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
           if (cok && m < p.M) {
             if constexpr (S32) {
               if (p.y) *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + colb) = o.u;
+              if (p.split_lo_off > 0) {
+                float w8[8];
+                h_unpack8<E>(o.u, w8);
+                H8 lo8;
+                lo8.u = make_uint4(fe_pack2((const E*)nullptr, v[0] - w8[0], v[1] - w8[1]), fe_pack2((const E*)nullptr, v[2] - w8[2], v[3] - w8[3]),
+                                   fe_pack2((const E*)nullptr, v[4] - w8[4], v[5] - w8[5]), fe_pack2((const E*)nullptr, v[6] - w8[6], v[7] - w8[7]));
+                *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + p.split_lo_off + colb) = lo8.u;
+              }
               if (p.y32) {      // (vec_epi with an fp32 output: Cout % 8 == 0, no pad_store)
                 *reinterpret_cast<float4*>(p.y32 + (size_t)m * p.ldy32 + colb) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(p.y32 + (size_t)m * p.ldy32 + colb + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -762,6 +790,8 @@ FE_WIDE_TILES(extern, f16)
 // the fp32-stream forms of the wide tiles: kernels_conv_{bf16,f16}_s32.hip
 #define FE_WIDE_TILES_S32(X, E)                                                                                  \
   X template void launch_bf16_variant<E, 2, 2, 2, 2, 1, 0, true, true>(const ConvParamsT<E>&, hipStream_t);  \
+  X template void launch_bf16_variant<E, 2, 2, 4, 2, 1, 0, true, true>(const ConvParamsT<E>&, hipStream_t);  \
+  X template void launch_bf16_variant<E, 2, 4, 4, 2, 1, 0, true, true>(const ConvParamsT<E>&, hipStream_t);  \
   X template void launch_bf16_variant<E, 2, 2, 2, 2, 1, 0, false, true>(const ConvParamsT<E>&, hipStream_t);
 FE_WIDE_TILES_S32(extern, bf16)
 FE_WIDE_TILES_S32(extern, f16)

@@ -240,6 +240,7 @@ struct ConvParamsT {
   float* y32; int ldy32;
   unsigned r32_span, y32_span;      // set by launch_conv_bf16: byte spans for buffer addressing
   int a_wrap;                       // 2-byte GEMM form: > 0 = the A row holds only a_wrap * 32 columns and is read again from column 0 after them
+  int split_lo_off;                 // 2-byte fp32-stream forms: > 0 = split-pair output, hi at column c and lo = round(v - hi) at column split_lo_off + c of y
   int exact_act;                    // 2-byte fp32-stream forms: erf GELU instead of the tanh form (results that are NOT rounded to 2 bytes)
 };
 using ConvParams = ConvParamsT<float>;
@@ -369,6 +370,10 @@ void launch_attention(const bf16* q, int ldq, const bf16* k, int ldk, const bf16
                       int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s);
 void launch_attention(const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int lp, const float* bv, f16* o,
                       int ldo, int B, int H, int Lq, int Lk, int dmodel, int causal, hipStream_t s);
+// split-operand attention (kernels_attn_split.hip): q / k rows [.][ld] with hi at column c and lo at lo_off + c, V^T as two planes,
+// output rows [.][ldo] as hi | lo (o_lo_off)
+void launch_attention_split(const f16* q, const f16* k, int ld, int lo_off, const f16* vt_hi, const f16* vt_lo, int lp, f16* o, int ldo, int o_lo_off,
+                            int B, int H, int Lq, int Lk, int dmodel, hipStream_t s);
 // M <= 32 rows: one wave per output column (kernels_misc.hip); TI / TW / TO = activation / weight / output element types
 template <class TI, class TW, class TO>
 void launch_gemm_skinny(const TI* x, int ldx, const TW* w, int ldw, const float* scale, const float* shift, TO* y,

@@ -13,14 +13,18 @@ typedef ConvParamsT<FE_E> ConvParamsE;
 // The fp32-stream forms (p.res32 / p.y32): their own instantiations of a reduced tile set (no 16-channel-block units, no slim tiles:
 // the layers that carry an fp32 stream are the ResNet block outputs / downsample branches and the ViT projections).
 static void launch_bf16_tile_s32(const ConvParamsE& p, int tile, bool one_tap, hipStream_t s) {
-  // reduced tile set: 128x128 for every wide choice (with the fp32 residual / output quads beside 128 accumulator registers the
-  // 256-row wave tiles spill), 128x64 / 64x64 narrow; no slim tiles, no 16-channel-block units
-  if (tile == 8 || tile == 9) tile = 1;
+  // reduced tile set: no slim tiles, no 16-channel-block units. The 256-row wave tiles (GEMM form only) spill ~150 bytes per lane in
+  // this epilogue (the fp32 residual / output quads beside 128 accumulator registers) and measured SLOWER than 128x128 even on the
+  // split-operand GEMMs of the ViT tower (K' = 3072 .. 12288: 993 vs 1185 crops/s), so they are off unless asked for
+  static const int wide_k = getenv("FE_S32_WIDE_K") ? atoi(getenv("FE_S32_WIDE_K")) : 0x7fffffff;      // A/B hook
+  if ((tile == 8 || tile == 9) && !(one_tap && p.K >= wide_k)) tile = 1;
   if (tile == 3) tile = 7;
   if (tile == 5) tile = 4;
   if (one_tap) {
     switch (tile) {
       case 1: launch_bf16_variant<FE_E, 2, 2, 2, 2, 1, 0, true, true>(p, s); return;
+      case 8: launch_bf16_variant<FE_E, 2, 2, 4, 2, 1, 0, true, true>(p, s); return;
+      case 9: launch_bf16_variant<FE_E, 2, 4, 4, 2, 1, 0, true, true>(p, s); return;
       case 7: launch_bf16_variant<FE_E, 2, 2, 2, 1, 1, 0, true, true>(p, s); return;
       case 4: launch_bf16_variant<FE_E, 2, 2, 1, 1, 1, 0, true, true>(p, s); return;
       default: break;
@@ -66,7 +70,9 @@ void launch_conv_bf16(const ConvParamsE& p0, hipStream_t s) {
   FE_CHECK(p.x && p.w && (p.y || p.y32) && (!p.y || p.ldy >= p.Cout) && p.ldx >= acols, "conv_bf16: null operand or row stride below the channel count");
   FE_CHECK(p.a_wrap <= 0 || (p.KH * p.KW == 1 && p.Cin % 64 == 0 && p.Kp == p.Cin && p.a_wrap * 32 < p.Cin && p.Cin <= 2 * p.a_wrap * 32),
            "conv_bf16: a_wrap needs the GEMM form (1x1, K %% 64 == 0) and K <= twice the wrapped width");
-  const bool f32s = p.y32 || p.res32;      // fp32 residual / output streams (FE_PRECISION_RES32 models)
+  const bool f32s = p.y32 || p.res32 || p.split_lo_off > 0;      // fp32 residual / output streams (FE_PRECISION_RES32 models), split-pair outputs
+  FE_CHECK(p.split_lo_off <= 0 || (p.y && !p.y32 && !p.res32 && !p.res && !p.gate && p.split_lo_off % 8 == 0 && p.split_lo_off >= p.Cout && p.ldy >= p.split_lo_off + p.Cout),
+           "conv_bf16: split-pair output needs y rows of at least split_lo_off + Cout columns and no residual / gate / fp32 output");
   FE_CHECK(!f32s || ((!p.y32 || p.ldy32 >= p.Cout) && (!p.res32 || p.ldr32 >= p.Cout) && !p.res && !p.pad_store && p.batch <= 1 && p.act != ACT_PRELU),
            "conv_bf16: fp32 streams take no 2-byte residual / pad_store / batched launch / PReLU");
   if (!p.y) p.ldy = 0;
@@ -144,14 +150,14 @@ void launch_conv_bf16(const ConvParamsE& p0, hipStream_t s) {
   if (tile == 9 && !(ntaps == 1 && p.Cin % 64 == 0 && p.Kp == p.Cin && p.cb == 32)) tile = 8;
   // the wide tiles' epilogue (h_epilogue_wide) addresses y / res / gate through 32-bit buffer offsets in 8-byte quads
   const int climit = p.pad_store ? ((p.Cout + 7) & ~7) : p.Cout;
-  const unsigned long long ysp = ((unsigned long long)(p.M - 1) * p.ldy + climit) * 2;
+  const unsigned long long ysp = ((unsigned long long)(p.M - 1) * p.ldy + climit + (p.split_lo_off > 0 ? p.split_lo_off : 0)) * 2;
   const unsigned long long rsp = p.res ? ((unsigned long long)(p.M - 1) * p.ldr + p.Cout) * 2 : 0;
   const unsigned long long gsp = p.gate ? ((unsigned long long)(p.M - 1) * p.ldg + (p.gate_c1 ? 1 : p.Cout)) * 2 : 0;
   const unsigned long long y32sp = p.y32 ? ((unsigned long long)(p.M - 1) * p.ldy32 + p.Cout) * 4 : 0;
   const unsigned long long r32sp = p.res32 ? ((unsigned long long)(p.M - 1) * p.ldr32 + p.Cout) * 4 : 0;
   // (a fp32 residual without an fp32 output has no wide form: h_epilogue_wide32 always writes p.y32)
   const bool wide_ok = p.vec_epi && ysp < 0xFFFFFF00ull && rsp < 0xFFFFFF00ull && gsp < 0xFFFFFF00ull && (p.pad_store ? (!p.scale && !p.shift && !p.res && !p.gate) : true) &&
-                       y32sp < 0xFFFFFF00ull && r32sp < 0xFFFFFF00ull && (!f32s || (p.y32 && !p.gate));
+                       y32sp < 0xFFFFFF00ull && r32sp < 0xFFFFFF00ull && (!f32s || ((p.y32 || p.split_lo_off > 0) && !p.gate));
   p.y_span = p.y ? (unsigned)ysp : 0u; p.r_span = (unsigned)rsp; p.g_span = (unsigned)gsp;
   p.y32_span = (unsigned)y32sp; p.r32_span = (unsigned)r32sp;
   if ((tile == 1 || tile == 8 || tile == 9) && !wide_ok) tile = 7;

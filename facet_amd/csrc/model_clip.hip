@@ -78,7 +78,7 @@ void build_clip(ClipModel& m, const WeightStore& ws) {
       std::vector<float> cs(3 * d, 1.0f);      // q = (x Wq^T + bq) / sqrt(head_dim): scaled after the bias, like build_mha
       for (int i = 0; i < d; ++i) cs[i] = 1.0f / std::sqrt((float)(d / m.heads));
       w.qkv3 = pack_split(m.dw, 3 * d, d, Wi.data.data(), Bi.data.data(), 3, &cs);
-      w.out2 = pack_split(m.dw, d, d, ws.get(b + ".attn.out_proj.weight").data.data(), ws.get(b + ".attn.out_proj.bias").data.data(), 2);
+      w.out2 = pack_split(m.dw, d, d, ws.get(b + ".attn.out_proj.weight").data.data(), ws.get(b + ".attn.out_proj.bias").data.data(), 3);
       const HostTensor& Wf = ws.get(b + ".mlp.c_fc.weight");
       w.fc3 = pack_split(m.dw, (int)Wf.shape[0], d, Wf.data.data(), ws.get(b + ".mlp.c_fc.bias").data.data(), 3);
       const HostTensor& Wp = ws.get(b + ".mlp.c_proj.weight");
@@ -268,14 +268,15 @@ template void clip_forward<f16, float>(Ctx&, const ClipModel&, const Tensor&, fl
 // y = act(A . W3^T * scale + shift) (+ res32): A = fp16 rows holding a_cols columns ([xh | xl], or the plain x), W3 = pack_split's rows
 // of K' = w.KpH columns; the kernel reads A's columns 0 .. a_cols-1 and then, wrapped, 0 .. K' - a_cols - 1. Output: fp16 rows (y16) or
 // fp32 rows (y32, with an optional fp32 residual): the fp32-stream form of the kernel.
+// pair_off > 0: y16 rows receive the result as a split pair (hi at column n, lo at column pair_off + n).
 static void gemm_split(Ctx& c, const ConvW& w, const f16* a, int lda, int a_cols, int M, f16* y16, int ldy16, float* y32, int ldy32, const float* res32, int ldr32,
-                       int act) {
+                       int act, int pair_off = 0) {
   ConvParamsT<f16> p{};
   p.x = a; p.ldx = lda; p.w = (const f16*)w.wh; p.ldw = w.KpH; p.scale = w.scale; p.shift = w.shift;
   p.y = y16; p.ldy = ldy16; p.y32 = y32; p.ldy32 = ldy32; p.res32 = res32; p.ldr32 = ldr32;
   p.N = 1; p.H = 1; p.W = M; p.Ho = 1; p.Wo = M; p.M = M; p.Cin = w.KpH; p.Cout = w.Cout;
   p.KH = p.KW = 1; p.sh = p.sw = p.dh = p.dw = 1; p.K = w.KpH; p.Kp = w.KpH; p.cb = 32;
-  p.act = act; p.a_wrap = a_cols / 32; p.exact_act = 1;
+  p.act = act; p.a_wrap = a_cols / 32; p.exact_act = 1; p.split_lo_off = pair_off;
   FE_CHECK(a_cols % 64 == 0 && a_cols < w.KpH, "gemm_split: operand widths");
   launch_conv_bf16(p, c.stream);
   // algorithmic = the layer's 2 M K N; executed = the two or three operand products the matrix cores really ran (flops_saved < 0)
@@ -283,14 +284,14 @@ static void gemm_split(Ctx& c, const ConvW& w, const f16* a, int lda, int a_cols
   c.flops_accum += alg; c.flops_saved -= exec - alg; c.flops_half += exec;
 }
 
-// vt[b][c][t] = qkv[b*T + t][2d + c] for t < T, 0 for T <= t < Lp   (V of the fused projection, transposed for the attention kernel)
-__global__ void clip_v_transpose_kernel(const f16* __restrict__ qkv, int ld, f16* __restrict__ vt, int B, int T, int Lp, int d) {
+// vt[b][c][t] = src[b*T + t][col0 + c] for t < T, 0 for T <= t < Lp   (a V plane of the fused projection, transposed for the attention kernel)
+__global__ void clip_v_transpose_kernel(const f16* __restrict__ src, int ld, int col0, f16* __restrict__ vt, int B, int T, int Lp, int d) {
   __shared__ f16 tile[32][33];
   const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows per pass
   for (int r = ty; r < 32; r += 8) {
     const int t = t0 + r;
-    tile[r][tx] = t < T ? qkv[((size_t)b * T + t) * ld + 2 * d + c0 + tx] : (f16)0.f;
+    tile[r][tx] = t < T ? src[((size_t)b * T + t) * ld + col0 + c0 + tx] : (f16)0.f;
   }
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
@@ -299,6 +300,9 @@ __global__ void clip_v_transpose_kernel(const f16* __restrict__ qkv, int ld, f16
   }
 }
 
+// Every tensor between two layers is either the fp32 token stream or an fp16 PAIR (hi | lo): LayerNorm writes pairs, the fused q|k|v
+// projection and c_fc write pairs from their epilogues, attention (kernels_attn_split.hip) reads and writes pairs, out_proj and c_proj
+// add into the fp32 stream. No activation is ever rounded to a single fp16.
 void clip_forward_split3(Ctx& c, const ClipModel& m, const Tensor& x, float* feat) {
   FE_CHECK(m.split3, "clip: the tower was not committed under FE_PRECISION_SPLIT3");
   const size_t mark = c.arena.mark();
@@ -319,30 +323,32 @@ void clip_forward_split3(Ctx& c, const ClipModel& m, const Tensor& x, float* fea
   hipLaunchKernelGGL(clip_embed_kernel<float>, dim3(2048), dim3(256), 0, c.stream, (const float*)tok, tok, m.cls, m.pos, B, Tk, d);
   FE_HIP(hipGetLastError());
   float* xa = c.arena.array<float>((size_t)rows * d);
-  f16* nb = c.arena.array<f16>((size_t)rows * 2 * d);          // LayerNorm output as [hi | lo]
-  f16* qkv = c.arena.array<f16>((size_t)rows * 3 * d);
-  f16* vt = c.arena.array<f16>((size_t)B * d * Lp);
-  f16* ao = c.arena.array<f16>((size_t)rows * d);
-  float* h32 = c.arena.array<float>((size_t)rows * ff);
-  f16* hb = c.arena.array<f16>((size_t)rows * 2 * ff);
+  f16* nb = c.arena.array<f16>((size_t)rows * 2 * d);          // LayerNorm output [hi(d) | lo(d)]
+  f16* qkv = c.arena.array<f16>((size_t)rows * 6 * d);         // [q k v hi (3d) | q k v lo (3d)]
+  f16* vth = c.arena.array<f16>((size_t)B * d * Lp);
+  f16* vtl = c.arena.array<f16>((size_t)B * d * Lp);
+  f16* ao = c.arena.array<f16>((size_t)rows * 2 * d);          // attention output [hi | lo]
+  f16* hb = c.arena.array<f16>((size_t)rows * 2 * ff);         // GELU(c_fc) [hi(ff) | lo(ff)]
   launch_layernorm(tok, d, xa, d, m.ln_pre.g, m.ln_pre.b, rows, d, m.ln_pre.eps, c.stream);
   float* cur = xa;
   float* other = tok;
   for (const ClipBlockW& w : m.blocks) {
     launch_layernorm_split(cur, d, nb, 2 * d, w.ln1.g, w.ln1.b, rows, d, w.ln1.eps, c.stream);
-    gemm_split(c, w.qkv3, nb, 2 * d, 2 * d, rows, qkv, 3 * d, nullptr, 0, nullptr, 0, ACT_NONE);          // q (pre-scaled) | k | v, biases included
-    hipLaunchKernelGGL(clip_v_transpose_kernel, dim3(Lp / 32, d / 32, B), dim3(256), 0, c.stream, (const f16*)qkv, 3 * d, vt, B, Tk, Lp, d);
-    launch_attention((const f16*)qkv, 3 * d, (const f16*)(qkv + d), 3 * d, (const f16*)vt, Lp, m.zero_bias, ao, d, B, H, Tk, Tk, d, 0, c.stream);
-    c.flops_accum += 4.0 * B * H * (double)Tk * Tk * 64; c.flops_half += 4.0 * B * H * (double)Tk * Tk * 64;
-    gemm_split(c, w.out2, ao, d, d, rows, nullptr, 0, other, d, cur, d, ACT_NONE);                          // other = cur + out_proj(attn)
+    gemm_split(c, w.qkv3, nb, 2 * d, 2 * d, rows, qkv, 6 * d, nullptr, 0, nullptr, 0, ACT_NONE, 3 * d);      // q (pre-scaled) | k | v, biases included
+    hipLaunchKernelGGL(clip_v_transpose_kernel, dim3(Lp / 32, d / 32, B), dim3(256), 0, c.stream, (const f16*)qkv, 6 * d, 2 * d, vth, B, Tk, Lp, d);
+    hipLaunchKernelGGL(clip_v_transpose_kernel, dim3(Lp / 32, d / 32, B), dim3(256), 0, c.stream, (const f16*)qkv, 6 * d, 5 * d, vtl, B, Tk, Lp, d);
+    launch_attention_split((const f16*)qkv, (const f16*)(qkv + d), 6 * d, 3 * d, (const f16*)vth, (const f16*)vtl, Lp, ao, 2 * d, d, B, H, Tk, Tk, d, c.stream);
+    c.flops_accum += 4.0 * B * H * (double)Tk * Tk * 64; c.flops_saved -= 8.0 * B * H * (double)Tk * Tk * 64; c.flops_half += 12.0 * B * H * (double)Tk * Tk * 64;
+    gemm_split(c, w.out2, ao, 2 * d, 2 * d, rows, nullptr, 0, other, d, cur, d, ACT_NONE);                  // other = cur + out_proj(attn)
     launch_layernorm_split(other, d, nb, 2 * d, w.ln2.g, w.ln2.b, rows, d, w.ln2.eps, c.stream);
-    gemm_split(c, w.fc3, nb, 2 * d, 2 * d, rows, nullptr, 0, h32, ff, nullptr, 0, ACT_GELU);                // erf GELU, fp32 out
-    launch_split_hi_lo(h32, hb, (size_t)rows, ff, c.stream);
+    gemm_split(c, w.fc3, nb, 2 * d, 2 * d, rows, hb, 2 * ff, nullptr, 0, nullptr, 0, ACT_GELU, ff);          // erf GELU, pair out
     gemm_split(c, w.proj3, hb, 2 * ff, 2 * ff, rows, nullptr, 0, cur, d, other, d, ACT_NONE);               // cur = other + c_proj(h)
   }
   float* pooled = c.arena.array<float>((size_t)B * d);
   launch_layernorm(cur, Tk * d, pooled, d, m.ln_post.g, m.ln_post.b, B, d, m.ln_post.eps, c.stream);
-  linear_forward_xf32(c, m.proj, PREC_F16, (const float*)pooled, d, B, feat, m.out_dim, ACT_NONE);      // fp32 rows on the fp16 projection weights
+  // the projection of the pooled token runs on the fp32 copy of its weights: ONE layer of singly-rounded fp16 weights alone costs
+  // 2.5e-4 on the features (measured) - relative weight errors of a dot product do not average out
+  linear_forward(c, m.proj, (const float*)pooled, d, B, feat, m.out_dim, ACT_NONE);
   c.arena.rewind(mark);
 }
 
