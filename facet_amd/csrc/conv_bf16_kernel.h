@@ -159,9 +159,11 @@ __device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const C
 // lanes per 128-byte row segment. ACTK: 0 none, 1 ReLU, -1 named by p.act. No gate, no pad_store.
 // OUT == 3: the split-pair output of the split-operand GEMMs (ClipModel::split3) - no fp32 rows; the result leaves as two 2-byte
 // values per element, hi = round(v) at column c and lo = round(v - hi) at column p.split_lo_off + c of the same row of p.y.
+// OUT == 4: the pair output with BOTH 2-byte images staged at once (stage2 = a second wave-private region): the accumulators die after
+// the first pass - the form of the 256-row wave tiles, whose 128 accumulator registers leave no room to carry the low parts.
 template <class E, int TM, int TN, int ACTK, int OUT>
 __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const ConvParamsT<E>& p, const int row0, const int col0,
-                                                  const int lane, char* const stage) {
+                                                  const int lane, char* const stage, char* const stage2 = nullptr) {
   static_assert(TN == 2, "wide tiles");
   constexpr unsigned OOB = 0xFFFFFFF0u;
   constexpr int PITCH = TN * 64 + 16;
@@ -198,15 +200,21 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
           float x = acc[i][j][4 * g + e] * (hs ? sc[e] : 1.f) + sf[e];
           if (!p.res_after_act) x += rvi[e];
           if (ACTK == 1) x = x > 0.f ? x : 0.f;
+          else if (ACTK == -2) x = fe_apply_act(x, p.act);      // exact forms only (erf GELU): the split-pair outputs are not rounded to one 2-byte value
           else if (ACTK < 0) x = p.exact_act ? fe_apply_act(x, p.act) : fe_apply_act_fast(x, p.act);
           if (p.res_after_act) x += rvi[e];
           v[e] = x;
-          acc[i][j][4 * g + e] = OUT == 3 ? x - (float)(E)x : x;          // kept for the second pass below (OUT == 3: the low part)
+          if (OUT != 4) acc[i][j][4 * g + e] = OUT == 3 ? x - (float)(E)x : x;          // kept for the second pass below (OUT == 3: the low part)
         }
         if (OUT >= 2) {
           h_v2u o;
           o.x = fe_pack2((const E*)nullptr, v[0], v[1]); o.y = fe_pack2((const E*)nullptr, v[2], v[3]);
           *reinterpret_cast<h_v2u*>(stage + (32 * i + r) * PITCH + (32 * j + 8 * g + 4 * h) * 2) = o;
+        }
+        if (OUT == 4) {
+          h_v2u o;
+          o.x = fe_pack2((const E*)nullptr, v[0] - (float)(E)v[0], v[1] - (float)(E)v[1]); o.y = fe_pack2((const E*)nullptr, v[2] - (float)(E)v[2], v[3] - (float)(E)v[3]);
+          *reinterpret_cast<h_v2u*>(stage2 + (32 * i + r) * PITCH + (32 * j + 8 * g + 4 * h) * 2) = o;
         }
       }
       // one (column block, quad) group at a time: hoisting the residual quads of all eight groups (4 VGPRs x TM each) beside the
@@ -214,19 +222,20 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  auto store_e_image = [&](const unsigned col_off_bytes) __attribute__((always_inline)) {      // the staged 2-byte image of the wave tile -> 16-byte row stores
+  auto store_e_image = [&](const unsigned col_off_bytes, const char* const img) __attribute__((always_inline)) {      // a staged 2-byte image of the wave tile -> 16-byte row stores
     constexpr int LPR = TN * 4, RPI = 64 / LPR;
     const int lr = lane / LPR, lc = lane % LPR;
     const int c = col0 + lc * 8;
 #pragma unroll
     for (int it = 0; it < TM * 32 / RPI; ++it) {
       const int row = it * RPI + lr, m = row0 + row;
-      const h_v4 d = *reinterpret_cast<const h_v4*>(stage + row * PITCH + lc * 16);
+      const h_v4 d = *reinterpret_cast<const h_v4*>(img + row * PITCH + lc * 16);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(h_v4u, d), ry, (int)((m < p.M && c < p.Cout) ? (unsigned)m * (unsigned)(p.ldy * 2) + (unsigned)c * 2u + col_off_bytes : OOB), 0, 0);
       if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if (OUT >= 2) store_e_image(0u);
+  if (OUT >= 2) store_e_image(0u, stage);
+  if (OUT == 4) { store_e_image((unsigned)p.split_lo_off * 2u, stage2); return; }
   if (OUT == 3) {      // second image: the low parts, at column split_lo_off
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -240,7 +249,7 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
           *reinterpret_cast<h_v2u*>(stage + (32 * i + r) * PITCH + (32 * j + 8 * g + 4 * h) * 2) = o;
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    store_e_image((unsigned)p.split_lo_off * 2u);
+    store_e_image((unsigned)p.split_lo_off * 2u, stage);
     return;
   }
   // fp32 rows: one 32-column block of the wave tile at a time through the same staging region
@@ -272,7 +281,9 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
 // ONE_TAP: 1x1 kernels (GEMMs) - no tap masks, the K offset of a slab goes into the scalar offset of the buffer load.
 // S32: the fp32-stream form of the layer (p.res32 / p.y32, FE_PRECISION_RES32 models) - its own instantiations, so the plain kernels
 // keep their register budgets (with the fp32 residual quads inlined beside the eleven plain forms the 256-row tiles spilled).
-template <class E, int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false, bool S32 = false>
+// S32 == 2 / 3: ONE form per kernel (2: fp32 rows out, optional fp32 residual, no activation; 3: split-pair rows out, activation named
+// by p.act) - the 256-row wave tiles, which spill when several of these forms are inlined side by side.
+template <class E, int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false, int S32 = 0>
 __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8 ? 2 : (TM * TN >= 4 ? (WGM * TM * 32 % 64 == 0 && WGN * TN * 32 % 64 == 0 ? 3 : 2) : 3)))) void conv_bf16_kernel(ConvParamsT<E> p, const int ntiles, const int ntotal) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int NW = WGM * WGN;                              // waves per workgroup: 4, or 8 for the 256x256 tile
@@ -406,7 +417,19 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
       // straight-line forms of the combinations the models use; the rest (softplus gates, residual after the activation) take the
       // form that reads activation, gate and residual order from the parameters
       const bool plain = !p.gate && !(p.res && p.res_after_act);
-      if constexpr (S32) {      // fp32-stream forms (launch_conv_bf16 admits them only without gate / E-typed residual / pad_store)
+      if constexpr (S32 == 2) {
+        h_epilogue_wide32<E, TM, TN, 0, 1>(acc, p, row0, col0, lane, stage);
+        return;
+      } else if constexpr (S32 == 3) {
+#ifdef FE_PAIR_DUAL_STAGE
+        h_epilogue_wide32<E, TM, TN, -2, 4>(acc, p, row0, col0, lane, stage, stage + NW * (TM * 32) * (TN * 64 + 16));
+#else
+        // one staged image at a time (the low parts wait in the accumulator registers): half the LDS of the dual-stage form, so two
+        // workgroups still fit a CU - measured against it on the split-operand ViT GEMMs (profiles/r03_README.md)
+        h_epilogue_wide32<E, TM, TN, -2, 3>(acc, p, row0, col0, lane, stage);
+#endif
+        return;
+      } else if constexpr (S32 != 0) {      // fp32-stream forms (launch_conv_bf16 admits them only without gate / E-typed residual / pad_store)
         if (p.split_lo_off > 0) h_epilogue_wide32<E, TM, TN, -1, 3>(acc, p, row0, col0, lane, stage);                                  // split-pair output
         else if (!p.y && p.act == ACT_NONE && !p.res_after_act) h_epilogue_wide32<E, TM, TN, 0, 1>(acc, p, row0, col0, lane, stage);        // ViT projections
         else if (p.y && p.act == ACT_RELU && !p.res_after_act) h_epilogue_wide32<E, TM, TN, 1, 2>(acc, p, row0, col0, lane, stage);    // ResNet block outputs
@@ -758,12 +781,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
   }
 }
 
-template <class E, int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false, bool S32 = false>
+template <class E, int WGM, int WGN, int TM, int TN, int UNITS, int MODE = 0, bool ONE_TAP = false, int S32 = 0>
 void launch_bf16_variant(const ConvParamsT<E>& p, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
   constexpr size_t main_lds = (size_t)3 * (BM + BN) * 64 + (BN == 32 ? 4096 : 0);      // + the dummy pieces' scratch (32-column tiles)
-  constexpr size_t epi_lds = TN > 1 ? (size_t)(WGM * WGN) * (TM * 32) * (TN * 64 + 16)      // wide tiles: bf16 image of every wave's tile
+#ifdef FE_PAIR_DUAL_STAGE
+  constexpr int PAIR_IMAGES = 2;
+#else
+  constexpr int PAIR_IMAGES = 1;
+#endif
+  constexpr size_t epi_lds = TN > 1 ? (size_t)(S32 == 3 ? PAIR_IMAGES : 1) * (WGM * WGN) * (TM * 32) * (TN * 64 + 16)      // wide tiles: bf16 image of every wave's tile (two for the pair form)
                                     : (size_t)4 * 32 * (TN * 32 + 4) * sizeof(float);
   constexpr size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   auto kern = conv_bf16_kernel<E, WGM, WGN, TM, TN, UNITS, MODE, ONE_TAP, S32>;
@@ -789,10 +817,11 @@ FE_WIDE_TILES(extern, bf16)
 FE_WIDE_TILES(extern, f16)
 // the fp32-stream forms of the wide tiles: kernels_conv_{bf16,f16}_s32.hip
 #define FE_WIDE_TILES_S32(X, E)                                                                                  \
-  X template void launch_bf16_variant<E, 2, 2, 2, 2, 1, 0, true, true>(const ConvParamsT<E>&, hipStream_t);  \
-  X template void launch_bf16_variant<E, 2, 2, 4, 2, 1, 0, true, true>(const ConvParamsT<E>&, hipStream_t);  \
-  X template void launch_bf16_variant<E, 2, 4, 4, 2, 1, 0, true, true>(const ConvParamsT<E>&, hipStream_t);  \
-  X template void launch_bf16_variant<E, 2, 2, 2, 2, 1, 0, false, true>(const ConvParamsT<E>&, hipStream_t);
+  X template void launch_bf16_variant<E, 2, 2, 2, 2, 1, 0, true, 1>(const ConvParamsT<E>&, hipStream_t);     \
+  X template void launch_bf16_variant<E, 2, 2, 2, 2, 1, 0, false, 1>(const ConvParamsT<E>&, hipStream_t);    \
+  X template void launch_bf16_variant<E, 2, 2, 4, 2, 1, 0, true, 2>(const ConvParamsT<E>&, hipStream_t);     /* 256x128: fp32 rows */ \
+  X template void launch_bf16_variant<E, 2, 2, 4, 2, 1, 0, true, 3>(const ConvParamsT<E>&, hipStream_t);     /* 256x128: pair rows */ \
+  X template void launch_bf16_variant<E, 2, 4, 4, 2, 1, 0, true, 2>(const ConvParamsT<E>&, hipStream_t);     /* 256x256: fp32 rows */
 FE_WIDE_TILES_S32(extern, bf16)
 FE_WIDE_TILES_S32(extern, f16)
 

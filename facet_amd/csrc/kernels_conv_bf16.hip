@@ -13,27 +13,31 @@ typedef ConvParamsT<FE_E> ConvParamsE;
 // The fp32-stream forms (p.res32 / p.y32): their own instantiations of a reduced tile set (no 16-channel-block units, no slim tiles:
 // the layers that carry an fp32 stream are the ResNet block outputs / downsample branches and the ViT projections).
 static void launch_bf16_tile_s32(const ConvParamsE& p, int tile, bool one_tap, hipStream_t s) {
-  // reduced tile set: no slim tiles, no 16-channel-block units. The 256-row wave tiles (GEMM form only) spill ~150 bytes per lane in
-  // this epilogue (the fp32 residual / output quads beside 128 accumulator registers) and measured SLOWER than 128x128 even on the
-  // split-operand GEMMs of the ViT tower (K' = 3072 .. 12288: 993 vs 1185 crops/s), so they are off unless asked for
-  static const int wide_k = getenv("FE_S32_WIDE_K") ? atoi(getenv("FE_S32_WIDE_K")) : 0x7fffffff;      // A/B hook
-  if ((tile == 8 || tile == 9) && !(one_tap && p.K >= wide_k)) tile = 1;
+  // reduced tile set: no slim tiles, no 16-channel-block units. The 256-row wave tiles exist in the GEMM form with ONE epilogue form
+  // per kernel (with several fp32-stream forms inlined side by side they spill ~150 bytes per lane and ran slower than 128x128): fp32
+  // rows out (+ fp32 residual, no activation: the projections that add into the token stream) on 256x128 / 256x256, split-pair rows
+  // out on 256x128 (both 2-byte images staged at once: no room for that beside eight waves).
+  static const bool wide = getenv("FE_S32_NO_WIDE") == nullptr;      // A/B hook
+  const bool f32_form = p.y32 && !p.y && p.act == ACT_NONE && !p.res_after_act && p.split_lo_off <= 0;
+  const bool pair_form = p.split_lo_off > 0;
+  if ((tile == 8 || tile == 9) && !(wide && one_tap && (f32_form || pair_form))) tile = 1;
+  if (tile == 9 && pair_form) tile = 8;
   if (tile == 3) tile = 7;
   if (tile == 5) tile = 4;
   if (one_tap) {
     switch (tile) {
-      case 1: launch_bf16_variant<FE_E, 2, 2, 2, 2, 1, 0, true, true>(p, s); return;
-      case 8: launch_bf16_variant<FE_E, 2, 2, 4, 2, 1, 0, true, true>(p, s); return;
-      case 9: launch_bf16_variant<FE_E, 2, 4, 4, 2, 1, 0, true, true>(p, s); return;
-      case 7: launch_bf16_variant<FE_E, 2, 2, 2, 1, 1, 0, true, true>(p, s); return;
-      case 4: launch_bf16_variant<FE_E, 2, 2, 1, 1, 1, 0, true, true>(p, s); return;
+      case 1: launch_bf16_variant<FE_E, 2, 2, 2, 2, 1, 0, true, 1>(p, s); return;
+      case 8: if (pair_form) launch_bf16_variant<FE_E, 2, 2, 4, 2, 1, 0, true, 3>(p, s); else launch_bf16_variant<FE_E, 2, 2, 4, 2, 1, 0, true, 2>(p, s); return;
+      case 9: launch_bf16_variant<FE_E, 2, 4, 4, 2, 1, 0, true, 2>(p, s); return;
+      case 7: launch_bf16_variant<FE_E, 2, 2, 2, 1, 1, 0, true, 1>(p, s); return;
+      case 4: launch_bf16_variant<FE_E, 2, 2, 1, 1, 1, 0, true, 1>(p, s); return;
       default: break;
     }
   }
   switch (tile) {
-    case 1: launch_bf16_variant<FE_E, 2, 2, 2, 2, 1, 0, false, true>(p, s); break;
-    case 7: launch_bf16_variant<FE_E, 2, 2, 2, 1, 1, 0, false, true>(p, s); break;
-    case 4: launch_bf16_variant<FE_E, 2, 2, 1, 1, 1, 0, false, true>(p, s); break;
+    case 1: launch_bf16_variant<FE_E, 2, 2, 2, 2, 1, 0, false, 1>(p, s); break;
+    case 7: launch_bf16_variant<FE_E, 2, 2, 2, 1, 1, 0, false, 1>(p, s); break;
+    case 4: launch_bf16_variant<FE_E, 2, 2, 1, 1, 1, 0, false, 1>(p, s); break;
     default: FE_CHECK(false, "conv_bf16: unknown tile %d", tile);
   }
 }
