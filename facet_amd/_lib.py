@@ -101,6 +101,7 @@ SIGNATURES = {
     "fe_vlm_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "fe_vlm_prefill": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), _f32p]),
     "fe_vlm_decode_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), _f32p]),
+    "fe_vlm_generate": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "fe_ensemble_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
                                     C.POINTER(C.c_int)]),
     "fe_u2netp_saliency": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
@@ -581,6 +582,23 @@ class Engine:
             position_ids = np.broadcast_to(np.arange(L, dtype=np.int32), (3, n, L))
         position_ids = np.ascontiguousarray(position_ids, dtype=np.int32)
         nxt_pos = position_ids.max(axis=(0, 2)) + 1            # [n_seq]
+        if not want_logits and forced_tokens is None:
+            # the product path: prefill, then every decode step on the device (fe_vlm_generate: captured graph, no host round trips)
+            first = self.vlm_prefill(tok, position_ids, max_seq=min(8192, L + max_new_tokens))
+            out = np.empty((n, max_new_tokens), np.int32)
+            out[:, 0] = first
+            if max_new_tokens > 1:
+                ft, fp = self._i32(first)
+                ps, pp = self._i32(np.broadcast_to(nxt_pos.astype(np.int32), (3, n)))
+                steps = np.empty((max_new_tokens - 1, n), np.int32)
+                self._ck(self.lib.fe_vlm_generate(self.h, fp, pp, n, max_new_tokens - 1, steps.ctypes.data_as(C.POINTER(C.c_int32))))
+                out[:, 1:] = steps.T
+            eos = [int(e) for e in eos_token_ids]
+            for b in range(n if eos else 0):      # generate() pads a finished sequence with its EOS id
+                hit = np.flatnonzero(np.isin(out[b], eos))
+                if hit.size:
+                    out[b, hit[0]:] = out[b, hit[0]]
+            return out
         out = np.zeros((n, max_new_tokens), np.int32)
         logits = []
         r = self.vlm_prefill(tok, position_ids, max_seq=min(8192, L + max_new_tokens), want_logits=want_logits)

@@ -1293,6 +1293,23 @@ int fe_vlm_prefill(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_i
   vlm_step(ctx, tokens, position_ids, n_seq, len, next_tokens, logits);
   FE_API_END(ctx)
 }
+int fe_vlm_generate(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int n_steps, int32_t* out_tokens) {
+  FE_API_BEGIN(ctx)
+  if (!ctx->c.vlm) { ctx->c.err = "vlm weights not loaded"; return FE_ERR_NOT_LOADED; }
+  Ctx& C = ctx->c;
+  VlmModel& m = *C.vlm;
+  FE_CHECK(tokens && position_ids && out_tokens && n_steps > 0 && n_seq == m.cache_B && m.cur_len > 0, "generate: call fe_vlm_prefill for these %d sequences first", n_seq);
+  C.arena.reset();
+  int* d_tok = (int*)C.arena.alloc((size_t)n_seq * sizeof(int));
+  int* d_pos = (int*)C.arena.alloc((size_t)3 * n_seq * sizeof(int));
+  int* d_out = (int*)C.arena.alloc((size_t)n_steps * n_seq * sizeof(int));
+  FE_HIP(hipMemcpyAsync(d_tok, tokens, (size_t)n_seq * sizeof(int), hipMemcpyHostToDevice, C.stream));
+  FE_HIP(hipMemcpyAsync(d_pos, position_ids, (size_t)3 * n_seq * sizeof(int), hipMemcpyHostToDevice, C.stream));
+  vlm_decode_steps(C, m, d_tok, d_pos, n_seq, n_steps, d_out);
+  FE_HIP(hipMemcpyAsync(out_tokens, d_out, (size_t)n_steps * n_seq * sizeof(int), hipMemcpyDeviceToHost, C.stream));
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
 int fe_vlm_decode_step(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int32_t* next_tokens, float* logits) {
   FE_API_BEGIN(ctx)
   if (!ctx->c.vlm) { ctx->c.err = "vlm weights not loaded"; return FE_ERR_NOT_LOADED; }

@@ -340,7 +340,8 @@ struct VlmModel {
 };
 void build_vlm(VlmModel& m, const WeightStore& ws, const VlmConfig& cfg);
 void vlm_embed(Ctx& c, const VlmModel& m, const int* tok_dev, int rows, bf16* x);
-void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int* next_dev, float* logits_dev);
+void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int* next_dev, float* logits_dev, const int* len_dev = nullptr);
+void vlm_decode_steps(Ctx& c, VlmModel& m, int* tok_dev, int* pos_dev, int B, int n_steps, int* out_dev);
 
 void build_topiq_head(TopiqModel& m, const WeightStore& ws);
 // feats: the 5 pyramid levels for nb images; scores_dev: device [nb]

@@ -16,6 +16,11 @@
 
 namespace fe {
 
+__device__ __forceinline__ void h_unpack8_bf16(const uint4 u, float v[8]) {
+  const bf16* tag = nullptr;
+  fe_unpack2(tag, u.x, v[0], v[1]); fe_unpack2(tag, u.y, v[2], v[3]); fe_unpack2(tag, u.z, v[4], v[5]); fe_unpack2(tag, u.w, v[6], v[7]);
+}
+
 // ---- small row kernels ------------------------------------------------------------------------------------------------------------
 // x[row][:] = E[tok[row]][:]   (bf16 table)
 __global__ void vlm_embed_kernel(const int* __restrict__ tok, const bf16* __restrict__ E, bf16* __restrict__ x, int rows, int d, int vocab) {
@@ -55,7 +60,9 @@ __global__ void vlm_rmsnorm_kernel(const bf16* __restrict__ x, int ldx, const bf
 // [16, 24, 24, 16, 24, 24]); cos / sin are rounded to bf16 and x*cos, rotate_half(x)*sin and their sum are each rounded to bf16, as
 // apply_multimodal_rotary_pos_emb does on bf16 tensors. One thread per (row, head, pair d < 64).
 __global__ void vlm_rope_cache_kernel(const bf16* __restrict__ qkv, const int* __restrict__ pos, const float* __restrict__ inv_freq, bf16* __restrict__ q_out,
-                                      bf16* __restrict__ kc, bf16* __restrict__ vc, int rows, int L, int nh, int nkv, int s0, int s1, int start, int max_seq) {
+                                      bf16* __restrict__ kc, bf16* __restrict__ vc, int rows, int L, int nh, int nkv, int s0, int s1, int start, int max_seq,
+                                      const int* __restrict__ start_dev) {
+  if (start_dev) start = *start_dev;      // decode steps replayed from a captured graph: the cache length lives in device memory
   const int heads = nh + 2 * nkv;
   const size_t total = (size_t)rows * heads * 64;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -259,7 +266,8 @@ __global__ __launch_bounds__(256, 2) void vlm_attn_prefill_kernel(const VlmAttnP
 // ---- decode attention: one query per (sequence, head) over the whole cache - a pure streaming pass over K then V (HBM-bound: the
 // keys and values of a head are read once per step). One workgroup per (b, head): scores -> LDS, softmax, weighted sum of V rows.
 __global__ __launch_bounds__(256) void vlm_attn_decode_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kc, const bf16* __restrict__ vc, bf16* __restrict__ o,
-                                                              int nh, int nkv, int Lk, int max_seq, float scale) {
+                                                              int nh, int nkv, int Lk, int max_seq, float scale, const int* __restrict__ len_dev) {
+  if (len_dev) Lk = *len_dev + 1;       // (graph replay: keys 0 .. cache length, the new token included)
   extern __shared__ float sc[];        // [Lk] scores / probabilities, then 4 x 128 partial outputs
   __shared__ float qs[128];
   __shared__ float red[8];
@@ -313,6 +321,84 @@ __global__ __launch_bounds__(256) void vlm_attn_decode_kernel(const bf16* __rest
   part[wave * 128 + 2 * lane] = a0; part[wave * 128 + 2 * lane + 1] = a1;
   __syncthreads();
   if (t < 128) o[((size_t)b * nh + head) * 128 + t] = (bf16)(part[t] + part[128 + t] + part[256 + t] + part[384 + t]);
+}
+
+// ---- decode GEMV: y[m][n] = sum_k x[m][k] w[n][k] (+ bias) for M <= 4 sequences - the shape of every projection of a decode step at the
+// reference's batch sizes (vlm_batch_size 2, models/vlm_tagger.py:76). Pure weight streaming: one wave per TWO output columns, 16-byte
+// loads (8 weights per lane and row), the M activation rows come from L1 / L2; fp32 accumulation, one rounding to bf16 (or fp32 out
+// for the logits). HBM-bound: N * K * 2 bytes per launch.
+template <int MR, class TO>
+__global__ __launch_bounds__(256) void vlm_gemv_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w, int ldw, const float* __restrict__ bias,
+                                                       TO* __restrict__ y, int ldy, int M, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 2;
+  if (n0 >= N) return;
+  const bool two = n0 + 1 < N;
+  const bf16* w0 = w + (size_t)n0 * ldw;
+  const bf16* w1 = w + (size_t)(two ? n0 + 1 : n0) * ldw;
+  float a0[MR], a1[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) { a0[m] = 0.f; a1[m] = 0.f; }
+  for (int k = lane * 8; k < K; k += 512) {
+    float u[8], v[8];
+    h_unpack8_bf16(*reinterpret_cast<const uint4*>(w0 + k), u);
+    h_unpack8_bf16(*reinterpret_cast<const uint4*>(w1 + k), v);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m < M) {
+        float xs[8];
+        h_unpack8_bf16(*reinterpret_cast<const uint4*>(x + (size_t)m * ldx + k), xs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a0[m] += xs[e] * u[e]; a1[m] += xs[e] * v[e]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0[m] += __shfl_xor(a0[m], o); a1[m] += __shfl_xor(a1[m], o); }
+  }
+  if (lane == 0) {
+    const float b0 = bias ? bias[n0] : 0.f, b1 = (bias && two) ? bias[n0 + 1] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m < M) {
+        stf(y + (size_t)m * ldy + n0, a0[m] + b0);
+        if (two) stf(y + (size_t)m * ldy + n0 + 1, a1[m] + b1);
+      }
+    }
+  }
+}
+template <class TO>
+static void vlm_gemv(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, TO* y, int ldy) {
+  FE_CHECK(w.wh && w.hprec == PREC_BF16 && w.KpH % 8 == 0 && ldx % 8 == 0 && M >= 1 && M <= 4 && !w.scale, "vlm_gemv: unsupported layer");
+  const int K = w.CinPadH, blocks = ((w.Cout + 1) / 2 * 64 + 255) / 256;
+  if (M == 1) hipLaunchKernelGGL((vlm_gemv_kernel<1, TO>), dim3(blocks), dim3(256), 0, c.stream, x, ldx, (const bf16*)w.wh, w.KpH, (const float*)w.shift, y, ldy, M, w.Cout, K);
+  else if (M == 2) hipLaunchKernelGGL((vlm_gemv_kernel<2, TO>), dim3(blocks), dim3(256), 0, c.stream, x, ldx, (const bf16*)w.wh, w.KpH, (const float*)w.shift, y, ldy, M, w.Cout, K);
+  else hipLaunchKernelGGL((vlm_gemv_kernel<4, TO>), dim3(blocks), dim3(256), 0, c.stream, x, ldx, (const bf16*)w.wh, w.KpH, (const float*)w.shift, y, ldy, M, w.Cout, K);
+  FE_HIP(hipGetLastError());
+  c.flops_accum += 2.0 * M * (double)w.Cin * w.Cout;
+}
+// y = x W^T (+ b) in bf16 for any row count: the streaming GEMV for up to 4 rows, the shared layer wrapper above that
+static void vlm_linear(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16* y, int ldy) {
+  if (M <= 4) vlm_gemv(c, w, x, ldx, M, y, ldy);
+  else linear_forward(c, w, x, ldx, M, y, ldy, ACT_NONE);
+}
+
+// device-resident decode state (graph replay): after a step, the chosen tokens become the next step's input, every position and the
+// cache length advance by one, and the tokens are appended to the output table [step][B]
+__global__ void vlm_advance_kernel(const int* __restrict__ next, int* __restrict__ tok, int* __restrict__ pos, int* __restrict__ len, int* __restrict__ step,
+                                   int* __restrict__ out, int B) {
+  const int b = threadIdx.x;
+  const int st = *step;
+  if (b < B) {
+    const int t = next[b];
+    tok[b] = t;
+    out[(size_t)st * B + b] = t;
+    pos[b] += 1; pos[B + b] += 1; pos[2 * B + b] += 1;
+  }
+  __syncthreads();
+  if (b == 0) { *len += 1; *step = st + 1; }
 }
 
 // ---- model ---------------------------------------------------------------------------------------------------------------------------
@@ -394,7 +480,9 @@ static inline int grid_n(size_t n, int per = 256) { size_t g = (n + per - 1) / p
 
 // x: [B*L][hidden] bf16 rows (token embeddings, image rows already in place), pos: device [3][B*L]. Appends L positions to the cache of
 // every sequence, leaves the next token of every sequence in next_dev [B] and (optionally) the bf16-rounded logits in logits_dev [B][vocab].
-void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int* next_dev, float* logits_dev) {
+// len_dev (decode steps only): the cache length in device memory, read by the kernels instead of the host's cur_len - the form a
+// captured graph replays.
+void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int* next_dev, float* logits_dev, const int* len_dev) {
   const VlmConfig& g = m.cfg;
   const int rows = B * L, d = m.hidden, nh = g.n_heads, nkv = g.n_kv_heads, qd = nh * 128, qkvd = (nh + 2 * nkv) * 128;
   const int start = m.cur_len, Lk = start + L;
@@ -411,12 +499,12 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
   for (size_t li = 0; li < m.layers.size(); ++li) {
     const VlmLayerW& w = m.layers[li];
     hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, (const bf16*)x, d, (const bf16*)w.ln1, n, d, rows, d, g.rms_eps);
-    linear_forward(c, w.qkv, (const bf16*)n, d, rows, qkv, qkvd, ACT_NONE);
+    vlm_linear(c, w.qkv, (const bf16*)n, d, rows, qkv, qkvd);
     hipLaunchKernelGGL(vlm_rope_cache_kernel, dim3(grid_n((size_t)rows * (nh + 2 * nkv) * 64)), dim3(256), 0, c.stream, (const bf16*)qkv, pos, (const float*)m.inv_freq, qr,
-                       m.kcache[li], m.vcache[li], rows, L, nh, nkv, g.mrope[0], g.mrope[1], start, m.max_seq);
+                       m.kcache[li], m.vcache[li], rows, L, nh, nkv, g.mrope[0], g.mrope[1], start, m.max_seq, L == 1 ? len_dev : (const int*)nullptr);
     if (L == 1) {
-      hipLaunchKernelGGL(vlm_attn_decode_kernel, dim3(B * nh), dim3(256), (size_t)std::max(Lk, 512) * sizeof(float), c.stream, (const bf16*)qr, (const bf16*)m.kcache[li],
-                         (const bf16*)m.vcache[li], ao, nh, nkv, Lk, m.max_seq, scale);
+      hipLaunchKernelGGL(vlm_attn_decode_kernel, dim3(B * nh), dim3(256), (size_t)std::max(len_dev ? m.max_seq : Lk, 512) * sizeof(float), c.stream, (const bf16*)qr,
+                         (const bf16*)m.kcache[li], (const bf16*)m.vcache[li], ao, nh, nkv, Lk, m.max_seq, scale, len_dev);
     } else {
       VlmAttnParams ap{qr, qd, m.kcache[li], m.vcache[li], ao, qd, B, nh, nkv, L, Lk, m.max_seq, start, scale};
       hipLaunchKernelGGL(vlm_attn_prefill_kernel, dim3((L + 127) / 128, B * nh), dim3(256), 0, c.stream, ap);
@@ -424,13 +512,13 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
     FE_HIP(hipGetLastError());
     c.flops_accum += 4.0 * B * nh * (double)L * (start + (L + 1) * 0.5) * 128;
     c.flops_half += 4.0 * B * nh * (double)L * (start + (L + 1) * 0.5) * 128;
-    linear_forward(c, w.o, (const bf16*)ao, qd, rows, br, d, ACT_NONE);
+    vlm_linear(c, w.o, (const bf16*)ao, qd, rows, br, d);
     hipLaunchKernelGGL(vlm_add_kernel, dim3(grid_n((size_t)rows * d / 4)), dim3(256), 0, c.stream, x, (const bf16*)br, (size_t)rows * d / 4);
     hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, (const bf16*)x, d, (const bf16*)w.ln2, n, d, rows, d, g.rms_eps);
-    linear_forward(c, w.gate, (const bf16*)n, d, rows, gg, m.inter, ACT_NONE);
-    linear_forward(c, w.up, (const bf16*)n, d, rows, uu, m.inter, ACT_NONE);
+    vlm_linear(c, w.gate, (const bf16*)n, d, rows, gg, m.inter);
+    vlm_linear(c, w.up, (const bf16*)n, d, rows, uu, m.inter);
     hipLaunchKernelGGL(vlm_silu_mul_kernel, dim3(grid_n((size_t)rows * m.inter / 4)), dim3(256), 0, c.stream, (const bf16*)gg, (const bf16*)uu, gg, (size_t)rows * m.inter / 4);
-    linear_forward(c, w.down, (const bf16*)gg, m.inter, rows, br, d, ACT_NONE);
+    vlm_linear(c, w.down, (const bf16*)gg, m.inter, rows, br, d);
     hipLaunchKernelGGL(vlm_add_kernel, dim3(grid_n((size_t)rows * d / 4)), dim3(256), 0, c.stream, x, (const bf16*)br, (size_t)rows * d / 4);
     FE_HIP(hipGetLastError());
   }
@@ -440,10 +528,52 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
   hipLaunchKernelGGL(vlm_last_rows_kernel, dim3((B * d + 255) / 256), dim3(256), 0, c.stream, (const bf16*)x, last, B, L, d);
   hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)B * 64)), dim3(256), 0, c.stream, (const bf16*)last, d, (const bf16*)m.norm, lastn, d, B, d, g.rms_eps);
   float* lg = logits_dev ? logits_dev : c.arena.array<float>((size_t)B * m.vocab);
-  linear_forward_f32(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab, ACT_NONE);
+  if (B <= 4) vlm_gemv(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab);
+  else linear_forward_f32(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab, ACT_NONE);
   hipLaunchKernelGGL(vlm_argmax_kernel, dim3(B), dim3(256), 0, c.stream, lg, m.vocab, next_dev);
   FE_HIP(hipGetLastError());
   m.cur_len = Lk;
+  c.arena.rewind(mark);
+}
+
+// n_steps greedy decode steps with NO host round trip: token ids, positions and the cache length live in device memory, one step is
+// captured into a HIP graph (~12 launches per layer: at the reference's batch sizes a step is launch-bound otherwise) and replayed.
+// tok_dev [B] holds the tokens to feed first (the prefill's choice), pos_dev [3][B] their positions; out_dev [n_steps][B] receives the
+// tokens chosen by the steps. Leaves cur_len advanced by n_steps.
+void vlm_decode_steps(Ctx& c, VlmModel& m, int* tok_dev, int* pos_dev, int B, int n_steps, int* out_dev) {
+  if (n_steps <= 0) return;
+  FE_CHECK(B == m.cache_B && m.cur_len > 0 && m.cur_len + n_steps <= m.max_seq, "vlm: %d more positions do not fit the cache (%d of %d used)", n_steps, m.cur_len, m.max_seq);
+  const size_t mark = c.arena.mark();
+  int* st = c.arena.array<int>(4);                 // [0] cache length, [1] step counter
+  int* next = c.arena.array<int>((size_t)B);
+  bf16* x = c.arena.array<bf16>((size_t)B * m.hidden);
+  const int init[2] = {m.cur_len, 0};
+  FE_HIP(hipMemcpyAsync(st, init, sizeof init, hipMemcpyHostToDevice, c.stream));
+  auto one_step = [&]() {
+    vlm_embed(c, m, tok_dev, B, x);
+    vlm_forward(c, m, x, pos_dev, B, 1, next, nullptr, st);
+    hipLaunchKernelGGL(vlm_advance_kernel, dim3(1), dim3(64 * ((B + 63) / 64)), 0, c.stream, (const int*)next, tok_dev, pos_dev, st, st + 1, out_dev, B);
+    FE_HIP(hipGetLastError());
+  };
+  const int len0 = m.cur_len;
+  one_step();                                      // outside the graph: first-use attributes (dynamic LDS sizes) are set here
+  static const bool no_graph = getenv("FE_VLM_NO_GRAPH") != nullptr;      // A/B hook
+  if (n_steps > 1 && !no_graph) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    FE_HIP(hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal));
+    m.cur_len = len0 + 1;                          // (host copy: only the cache-capacity check reads it during capture)
+    try { one_step(); } catch (...) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(c.stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
+    FE_HIP(hipStreamEndCapture(c.stream, &graph));
+    FE_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int s = 1; s < n_steps; ++s) FE_HIP(hipGraphLaunch(exec, c.stream));
+    FE_HIP(hipStreamSynchronize(c.stream));
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+  } else {
+    for (int s = 1; s < n_steps; ++s) { m.cur_len = len0 + s; one_step(); }
+  }
+  m.cur_len = len0 + n_steps;
   c.arena.rewind(mark);
 }
 

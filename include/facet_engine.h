@@ -96,6 +96,11 @@ int fe_vlm_dims(fe_ctx* ctx, int* dims8);
 int fe_vlm_prefill(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int len, int max_seq, int32_t* next_tokens,
                    float* logits);
 int fe_vlm_decode_step(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int32_t* next_tokens, float* logits);
+/* n_steps greedy decode steps without a host round trip (the loop generate() runs, models/vlm_tagger.py:255-259): the tokens to feed
+ * first (the prefill's choice, [n_seq]) and their positions ([3][n_seq]) go up once, token ids / positions / cache length then live in
+ * device memory and one captured HIP graph of a decode step is replayed; out_tokens [n_steps][n_seq] = the token each step chose.
+ * End-of-sequence handling is the caller's (cut the rows at the first EOS id). */
+int fe_vlm_generate(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int n_steps, int32_t* out_tokens);
 
 /* ---- device buffers (so callers can keep batches resident in HBM without torch) ------------- */
 int fe_dev_alloc(fe_ctx* ctx, size_t bytes, void** d_out);

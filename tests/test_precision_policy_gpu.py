@@ -165,3 +165,50 @@ def test_reference_gpu_policy_clip_f16_and_fast16(sds, oracle_nets):
         aes_rel = np.abs((aes + 1) * 5 - a_ref) / np.maximum(np.abs(a_ref), 1.0)
         print(f"[{pol}] clip 1-cos {one_minus_cos.max():.2e} aesthetic rel {aes_rel.max():.2e}")
         assert one_minus_cos.max() < cos_tol and aes_rel.max() < aes_tol
+
+
+def test_configs2_shaped_shard_of_128_images_properties(sds):
+    """BASELINE configs[2]'s shape - TOPIQ + SAMP-Net + faces, batch 128 - through score_shard (the multi-GPU step, world 1) under the
+    PARITY policy, with size-independent properties instead of an oracle run (128 images are minutes of CPU): the shard equals the
+    concatenation of two 64-image shards (batching / micro-batch independence up to tile-boundary rounding), scores are finite and
+    inside their ranges, a repeated image gets identical rows wherever it sits, score_dist rows sum to 1, the CLIP columns stay zero
+    (model not selected), face counts are integers in [0, max_faces]."""
+    from facet_amd import Engine
+    from facet_amd.sharding import score_shard
+    from facet_amd._lib import FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC, FE_FACE_FLOATS
+    from standins import synthetic_onnx as SO
+    N, HW = 128, 256
+    imgs = synthetic_images(77, N, HW, HW)
+    imgs[100] = imgs[3]; imgs[127] = imgs[3]          # the same image at three positions (two micro-batches apart)
+    e, fe = Engine(0, arena_bytes=8 << 30), Engine(0, arena_bytes=4 << 30)
+    try:
+        precision.load_models(e, "parity", {k: sds[k] for k in ("topiq", "u2netp", "samp_net")})
+        fe.graph_load(FE_GRAPH_FACE_DET, SO.scrfd_like(seed=12, size=160)[0])
+        fe.graph_load(FE_GRAPH_FACE_LMK, SO.landmark_like(seed=13)[0])
+        fe.graph_load(FE_GRAPH_FACE_REC, SO.arcface_iresnet(layers=(1, 1, 1, 1), seed=14)[0])
+        e.set_microbatch(16); fe.set_microbatch(16)
+        e.ensemble_select(5)
+        faces = ((160, 160), 0.3, 0.4, 2)
+        d = e.dev_alloc(imgs.nbytes); e.h2d(d, imgs)
+        rec, mask = score_shard(e, (d, N, HW, HW), N, 1, 0, faces=faces, face_engine=fe)
+        import ctypes
+        half = []
+        for i0 in (0, 64):
+            r, _ = score_shard(e, (ctypes.c_void_p(d.value + i0 * HW * HW * 3), 64, HW, HW), 64, 1, 0, faces=faces, face_engine=fe)
+            half.append(r)
+        e.dev_free(d)
+    finally:
+        e.close(); fe.close()
+    R = FE_RECORD_FLOATS + 1 + 2 * FE_FACE_FLOATS
+    assert mask == 5 and rec.shape == (N, R) and np.isfinite(rec).all()
+    both = np.concatenate(half, 0)
+    assert np.abs(rec[:, :21] - both[:, :21]).max() <= 1e-3 * max(1.0, np.abs(rec[:, :21]).max())      # fp16 TOPIQ: tile boundaries move with the batch
+    assert np.array_equal(rec[:, FE_RECORD_FLOATS], both[:, FE_RECORD_FLOATS])                        # face counts
+    assert (rec[:, 1] == 0).all() and (rec[:, 21:FE_RECORD_FLOATS] == 0).all()                        # CLIP not selected: aesthetic + embedding stay 0
+    assert np.abs(rec[:, 16:21].sum(1) - 1).max() < 1e-5 and (rec[:, 16:21] >= 0).all()               # score distribution
+    assert ((rec[:, 10:16] > 0) & (rec[:, 10:16] < 1)).all()                                          # sigmoid attributes
+    cnt = rec[:, FE_RECORD_FLOATS]
+    assert np.array_equal(cnt, np.rint(cnt)) and cnt.min() >= 0 and cnt.max() <= 2
+    for j in (100, 127):                                                                              # same pixels, other position in the batch
+        assert np.abs(rec[j, :21] - rec[3, :21]).max() <= 1e-3 * max(1.0, np.abs(rec[3, :21]).max())
+        assert rec[j, FE_RECORD_FLOATS] == rec[3, FE_RECORD_FLOATS]

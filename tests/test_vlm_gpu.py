@@ -59,6 +59,28 @@ def test_greedy_token_ids_identical_to_the_reference_class(vlm_engine):
     assert np.abs(logits.max(-1) - G["top_logit"]).max() <= 0.25          # the winning logit of every step
 
 
+def test_device_resident_generate_equals_the_stepwise_path(vlm_engine):
+    """fe_vlm_generate (token ids / positions / cache length in device memory, one captured HIP graph of a decode step replayed, the
+    streaming GEMV kernels of the small-batch decode) against the reference's tokens (planted checkpoint) and against the stepwise
+    fe_vlm_decode_step path on the random checkpoint, for 1, 2, 3 and 5 sequences (GEMV row counts 1 / 2 / 4 and the shared GEMM)."""
+    e = vlm_engine
+    e.load_weights(FE_MODEL_VLM, _planted(int(G["seed_w"])))
+    toks = e.vlm_generate(G["prompts"], G["tokens"].shape[1])
+    assert np.array_equal(toks, G["tokens"])
+    assert e.vlm_dims()["cur_len"] == G["prompts"].shape[1] + G["tokens"].shape[1] - 1
+    rng = np.random.default_rng(4)
+    for B in (1, 2, 3, 5):
+        p = rng.integers(0, 2048, (B, 19)).astype(np.int32)
+        fast = e.vlm_generate(p, 12)
+        slow, _ = e.vlm_generate(p, 12, want_logits=True)
+        assert np.array_equal(fast, slow), (B, fast, slow)
+    # EOS handling of the wrapper: the row is padded with the EOS id from its first occurrence on
+    p = G["prompts"][:1]
+    full = e.vlm_generate(p, 10)
+    cut = e.vlm_generate(p, 10, eos_token_ids=[int(full[0, 4])])
+    assert np.array_equal(cut[0, :5], full[0, :5]) and (cut[0, 4:] == full[0, 4]).all()
+
+
 def test_teacher_forced_logits_of_the_random_checkpoint(vlm_engine):
     e = vlm_engine
     e.load_weights(FE_MODEL_VLM, synthetic_state_dict("qwen2_5_vl_text_tiny", int(G["seed_w"])))
