@@ -330,19 +330,21 @@ __global__ __launch_bounds__(256) void vlm_attn_decode_kernel(const bf16* __rest
 template <int MR, class TO>
 __global__ __launch_bounds__(256) void vlm_gemv_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w, int ldw, const float* __restrict__ bias,
                                                        TO* __restrict__ y, int ldy, int M, int N, int K) {
-  const int lane = threadIdx.x & 63;
-  const int n0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 2;
-  if (n0 >= N) return;
+  // one workgroup = two output columns; its four waves take interleaved 512-column steps of K (so even the 3584-column projections put
+  // 7 waves on every SIMD) and meet in LDS
+  __shared__ float red[4][MR][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 2;
   const bool two = n0 + 1 < N;
   const bf16* w0 = w + (size_t)n0 * ldw;
   const bf16* w1 = w + (size_t)(two ? n0 + 1 : n0) * ldw;
   float a0[MR], a1[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) { a0[m] = 0.f; a1[m] = 0.f; }
-  for (int k = lane * 8; k < K; k += 512) {
+  auto fma8 = [&](const uint4 wa, const uint4 wb, const int k) __attribute__((always_inline)) {
     float u[8], v[8];
-    h_unpack8_bf16(*reinterpret_cast<const uint4*>(w0 + k), u);
-    h_unpack8_bf16(*reinterpret_cast<const uint4*>(w1 + k), v);
+    h_unpack8_bf16(wa, u);
+    h_unpack8_bf16(wb, v);
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       if (m < M) {
@@ -352,27 +354,48 @@ __global__ __launch_bounds__(256) void vlm_gemv_kernel(const bf16* __restrict__ 
         for (int e = 0; e < 8; ++e) { a0[m] += xs[e] * u[e]; a1[m] += xs[e] * v[e]; }
       }
     }
+  };
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));      // weights are read once per step: streamed past the caches
+  auto ldw8 = [](const bf16* ptr) __attribute__((always_inline)) {
+    const v4u a = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(ptr));
+    return make_uint4(a[0], a[1], a[2], a[3]);
+  };
+  int k = wave * 512 + lane * 8;
+  for (; k + 3 * 2048 < K; k += 4 * 2048) {      // four steps per trip, their eight weight loads issued before the first is used
+    uint4 wa[4], wb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wa[j] = ldw8(w0 + k + 2048 * j); wb[j] = ldw8(w1 + k + 2048 * j); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fma8(wa[j], wb[j], k + 2048 * j);
   }
+  for (; k + 2048 < K; k += 2 * 2048) {
+    const uint4 p0 = ldw8(w0 + k), q0 = ldw8(w1 + k), p1 = ldw8(w0 + k + 2048), q1 = ldw8(w1 + k + 2048);
+    fma8(p0, q0, k); fma8(p1, q1, k + 2048);
+  }
+  for (; k < K; k += 2048) fma8(ldw8(w0 + k), ldw8(w1 + k), k);
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a0[m] += __shfl_xor(a0[m], o); a1[m] += __shfl_xor(a1[m], o); }
   }
   if (lane == 0) {
-    const float b0 = bias ? bias[n0] : 0.f, b1 = (bias && two) ? bias[n0 + 1] : 0.f;
 #pragma unroll
-    for (int m = 0; m < MR; ++m) {
-      if (m < M) {
-        stf(y + (size_t)m * ldy + n0, a0[m] + b0);
-        if (two) stf(y + (size_t)m * ldy + n0 + 1, a1[m] + b1);
-      }
+    for (int m = 0; m < MR; ++m) { red[wave][m][0] = a0[m]; red[wave][m][1] = a1[m]; }
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < 2 * MR) {
+    const int m = t >> 1, c = t & 1;
+    if (m < M && (c == 0 || two)) {
+      const float v = (red[0][m][c] + red[1][m][c]) + (red[2][m][c] + red[3][m][c]) + (bias ? bias[n0 + c] : 0.f);
+      stf(y + (size_t)m * ldy + n0 + c, v);
     }
   }
 }
 template <class TO>
 static void vlm_gemv(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, TO* y, int ldy) {
   FE_CHECK(w.wh && w.hprec == PREC_BF16 && w.KpH % 8 == 0 && ldx % 8 == 0 && M >= 1 && M <= 4 && !w.scale, "vlm_gemv: unsupported layer");
-  const int K = w.CinPadH, blocks = ((w.Cout + 1) / 2 * 64 + 255) / 256;
+  const int K = w.CinPadH, blocks = (w.Cout + 1) / 2;
   if (M == 1) hipLaunchKernelGGL((vlm_gemv_kernel<1, TO>), dim3(blocks), dim3(256), 0, c.stream, x, ldx, (const bf16*)w.wh, w.KpH, (const float*)w.shift, y, ldy, M, w.Cout, K);
   else if (M == 2) hipLaunchKernelGGL((vlm_gemv_kernel<2, TO>), dim3(blocks), dim3(256), 0, c.stream, x, ldx, (const bf16*)w.wh, w.KpH, (const float*)w.shift, y, ldy, M, w.Cout, K);
   else hipLaunchKernelGGL((vlm_gemv_kernel<4, TO>), dim3(blocks), dim3(256), 0, c.stream, x, ldx, (const bf16*)w.wh, w.KpH, (const float*)w.shift, y, ldy, M, w.Cout, K);

@@ -172,7 +172,7 @@ def test_configs2_shaped_shard_of_128_images_properties(sds):
     PARITY policy, with size-independent properties instead of an oracle run (128 images are minutes of CPU): the shard equals the
     concatenation of two 64-image shards (batching / micro-batch independence up to tile-boundary rounding), scores are finite and
     inside their ranges, a repeated image gets identical rows wherever it sits, score_dist rows sum to 1, the CLIP columns stay zero
-    (model not selected), face counts are integers in [0, max_faces]."""
+    (model not selected), face counts are non-negative integers."""
     from facet_amd import Engine
     from facet_amd.sharding import score_shard
     from facet_amd._lib import FE_GRAPH_FACE_DET, FE_GRAPH_FACE_LMK, FE_GRAPH_FACE_REC, FE_FACE_FLOATS
@@ -208,7 +208,7 @@ def test_configs2_shaped_shard_of_128_images_properties(sds):
     assert np.abs(rec[:, 16:21].sum(1) - 1).max() < 1e-5 and (rec[:, 16:21] >= 0).all()               # score distribution
     assert ((rec[:, 10:16] > 0) & (rec[:, 10:16] < 1)).all()                                          # sigmoid attributes
     cnt = rec[:, FE_RECORD_FLOATS]
-    assert np.array_equal(cnt, np.rint(cnt)) and cnt.min() >= 0 and cnt.max() <= 2
+    assert np.array_equal(cnt, np.rint(cnt)) and cnt.min() >= 0      # faces found per image (the slots keep the best max_faces of them)
     for j in (100, 127):                                                                              # same pixels, other position in the batch
         assert np.abs(rec[j, :21] - rec[3, :21]).max() <= 1e-3 * max(1.0, np.abs(rec[3, :21]).max())
         assert rec[j, FE_RECORD_FLOATS] == rec[3, FE_RECORD_FLOATS]
