@@ -1,14 +1,14 @@
 #!/bin/bash
 # Matrix-core utilisation of a bench workload from one PMC pass -> gpurun_out/<tag>_<workload>[_bf16]_mfma_busy.summary.txt
-# usage: tools/pmc_mfma.sh <workload> [f32|bf16]
+# usage: tools/pmc_mfma.sh <workload> [policy: f32 | parity | fast16 | bf16 | reference_gpu | f16]
 # Counter budget (MI355X_MICROARCH.md, rocprofv3 PMC slots): SQ has 8 slots per pass, GRBM 2, independent of each other - this pass takes
 # 4 SQ counters + 1 GRBM counter and nothing from TCC; it runs with --kernel-trace only (no other trace domain beside --pmc).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 WL=${1:-topiq}
 DT=${2:-f32}
-TAG=${ROUND_TAG:-r02}
-KEY=$WL; [ "$DT" = bf16 ] && KEY=${WL}_bf16
+TAG=${ROUND_TAG:-r03}
+KEY=$WL; [ "$DT" != f32 ] && KEY=${WL}_$DT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_mfma
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma -- python3 $R/bench.py --workload $WL --dtype $DT --steps 1 --warmup 1 --batch 32 --cpu-sample 0 --no-sub > $R/gpurun_out/pmc_mfma.log 2>&1 || { echo "pass failed"; tail -5 $R/gpurun_out/pmc_mfma.log; exit 1; }
@@ -32,8 +32,12 @@ import json, re
 line = [l for l in open("$R/gpurun_out/pmc_mfma.log") if l.startswith("{")][-1]
 bench = json.loads(line)
 exec_flops = bench["roofline"]["executed_flops_per_image"] * 96      # three passes of 32 images: warm-up, timed, per-launch profile
-# one v_mfma_f32_32x32x2_f32 = 4096 FLOP and 64 cycles of its SIMD's pipe; one v_mfma_f32_32x32x16_bf16 = 32768 FLOP and 32 cycles
-expect_simd_cycles = exec_flops / 32768 * 32 if "$DT" == "bf16" else exec_flops / 4096 * 64
+# one v_mfma_f32_32x32x2_f32 = 4096 FLOP and 64 cycles of its SIMD's pipe; one v_mfma_f32_32x32x16_{bf16,f16} = 32768 FLOP and 32 cycles
+by = bench["roofline"].get("executed_flops_per_image_by_dtype")
+if by:      # a policy that mixes fp32 and 2-byte models: priced per dtype
+    expect_simd_cycles = by["f32"] * 96 / 4096 * 64 + by["2-byte"] * 96 / 32768 * 32
+else:
+    expect_simd_cycles = exec_flops / 32768 * 32 if isinstance(bench["roofline"]["peak"], (int, float)) and bench["roofline"]["peak"] > 1000 else exec_flops / 4096 * 64
 out = ["# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -- python3 bench.py --workload $WL --dtype $DT --steps 1 --warmup 1 --batch 32 --cpu-sample 0 --no-sub",
        "# per kernel (summed over launches): launches, share of elapsed cycles, matrix pipes busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8) / 1024 SIMDs, issue-stall share SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES",
        f"# whole run: sum SQ_VALU_MFMA_BUSY_CYCLES {tot_m:.4g}; MFMA pipe cycles implied by the engine's executed-FLOP counter {expect_simd_cycles:.4g} (ratio {tot_m / expect_simd_cycles:.3f});",
