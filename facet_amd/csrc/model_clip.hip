@@ -278,7 +278,22 @@ static void gemm_split(Ctx& c, const ConvW& w, const f16* a, int lda, int a_cols
   p.KH = p.KW = 1; p.sh = p.sw = p.dh = p.dw = 1; p.K = w.KpH; p.Kp = w.KpH; p.cb = 32;
   p.act = act; p.a_wrap = a_cols / 32; p.exact_act = 1; p.split_lo_off = pair_off;
   FE_CHECK(a_cols % 64 == 0 && a_cols < w.KpH, "gemm_split: operand widths");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c.profile) {
+    FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1));
+    FE_HIP(hipEventRecord(e0, c.stream));
+  }
   launch_conv_bf16(p, c.stream);
+  if (c.profile) {      // per-launch record (tools/perf_clip.py): EXECUTED FLOPs of the two or three operand products
+    FE_HIP(hipEventRecord(e1, c.stream));
+    FE_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FE_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    char nm[160];
+    snprintf(nm, sizeof nm, "f16 split gemm M=%d K'=%d (K=%d) N=%d %s", M, w.KpH, w.K, w.Cout, pair_off ? "pair out" : (y32 ? "fp32 out" : "f16 out"));
+    c.timings.push_back({nm, 2.0 * M * (double)w.KpH * w.Cout, 0.0, ms});
+  }
   // algorithmic = the layer's 2 M K N; executed = the two or three operand products the matrix cores really ran (flops_saved < 0)
   const double alg = 2.0 * M * (double)w.K * w.Cout, exec = 2.0 * M * (double)w.KpH * w.Cout;
   c.flops_accum += alg; c.flops_saved -= exec - alg; c.flops_half += exec;

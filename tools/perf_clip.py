@@ -5,7 +5,7 @@ from facet_amd import Engine
 from facet_amd._lib import FE_MODEL_CLIP, FE_MODEL_AESTHETIC
 from facet_amd.weights import synthetic_state_dict
 n, mb = 127, 32
-prec = 'bf16' if 'bf16' in sys.argv else 'f32'
+prec = next((a for a in sys.argv[1:] if a in ('f32', 'bf16', 'f16', 'f16+r32', 'bf16+r32', 'f16x3')), 'f32')
 eng = Engine(0, arena_bytes=40 << 30, precision=prec)
 eng.set_microbatch(mb)
 x = np.random.default_rng(0).standard_normal((n, 3, 224, 224), dtype=np.float32)

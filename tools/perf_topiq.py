@@ -10,7 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 mb = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 hw = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 level_only = len(sys.argv) > 4 and sys.argv[4] == "levels"
-prec = "bf16" if "bf16" in sys.argv else "f32"
+prec = "bf16" if "bf16" in sys.argv else ("f16" if "f16" in sys.argv else "f32")
 eng = Engine(0, arena_bytes=(4 + 2 * mb) << 30, precision=prec)
 eng.load_weights(FE_MODEL_TOPIQ, synthetic_state_dict("topiq", 3))
 imgs = synthetic_images(2, n, hw, hw)
