@@ -200,8 +200,8 @@ __device__ __forceinline__ void h_epilogue_wide32(h_f32x16 (&acc)[TM][TN], const
           float x = acc[i][j][4 * g + e] * (hs ? sc[e] : 1.f) + sf[e];
           if (!p.res_after_act) x += rvi[e];
           if (ACTK == 1) x = x > 0.f ? x : 0.f;
-          else if (ACTK == -2) x = fe_apply_act(x, p.act);      // exact forms only (erf GELU): the split-pair outputs are not rounded to one 2-byte value
-          else if (ACTK < 0) x = p.exact_act ? fe_apply_act(x, p.act) : fe_apply_act_fast(x, p.act);
+          else if (ACTK == -2) x = fe_apply_act_precise(x, p.act);      // erf GELU (A&S polynomial, 1.5e-7): the split-pair outputs are not rounded to one 2-byte value
+          else if (ACTK < 0) x = p.exact_act ? fe_apply_act_precise(x, p.act) : fe_apply_act_fast(x, p.act);
           if (p.res_after_act) x += rvi[e];
           v[e] = x;
           if (OUT != 4) acc[i][j][4 * g + e] = OUT == 3 ? x - (float)(E)x : x;          // kept for the second pass below (OUT == 3: the low part)
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 1 : (TM * TN >= 8
             float x = v[e] * sc[e] + sf[e];
             if (hres && !p.res_after_act) x += rf[e];
             if constexpr (MODE == 2) x = x > 0.f ? x : x * sl[e];
-            else x = (S32 && p.exact_act) ? fe_apply_act(x, p.act) : fe_apply_act_fast(x, p.act);
+            else x = (S32 && p.exact_act) ? fe_apply_act_precise(x, p.act) : fe_apply_act_fast(x, p.act);
             if (hres && p.res_after_act) x += rf[e];
             if (p.gate) x *= p.gate_c1 ? gs[it] : gf[e];
             if (!cfull && colb + e >= p.Cout) x = 0.f;
