@@ -101,6 +101,11 @@ SIGNATURES = {
     "fe_vlm_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "fe_vlm_prefill": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), _f32p]),
     "fe_vlm_decode_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), _f32p]),
+    "fe_vlm_vision_configure": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "fe_vlm_encode_images": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
+                                       C.POINTER(C.c_int32), C.c_int, _f32p]),
+    "fe_vlm_prefill_images": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int,
+                                        C.POINTER(C.c_int32), _f32p]),
     "fe_vlm_generate": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "fe_ensemble_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
                                     C.POINTER(C.c_int)]),
@@ -535,6 +540,26 @@ class Engine:
         ms = (C.c_int * 3)(*[int(v) for v in mrope_section])
         self._ck(self.lib.fe_vlm_configure(self.h, int(n_heads), int(n_kv_heads), int(head_dim), float(rope_theta), float(rms_eps), ms))
 
+    def vlm_vision_configure(self, n_heads=16, fullatt_block_indexes=(7, 15, 23, 31)):
+        """Vision-tower geometry read by the NEXT load_weights(FE_MODEL_VLM, ...) (Qwen2_5_VLVisionConfig; defaults = Qwen2.5-VL-7B)."""
+        fa = (C.c_int * max(1, len(fullatt_block_indexes)))(*[int(v) for v in fullatt_block_indexes])
+        self._ck(self.lib.fe_vlm_vision_configure(self.h, int(n_heads), fa, len(fullatt_block_indexes)))
+
+    def vlm_encode_images(self, pixel_values, patch_pos_hw, window_index, cu_window_seqlens, cu_seqlens, want_embeds=True):
+        """model.visual(pixel_values, grid_thw).pooler_output: float32 [n_patches / 4, hidden] (bf16 values), raster order; the embeddings
+        also stay on the device for the next vlm_prefill(..., image_rows=...). Index arrays: facet_amd.vlm_tagger.vision_indices."""
+        pv = np.ascontiguousarray(pixel_values, dtype=np.float32)
+        n = pv.shape[0]
+        pos, pp = self._i32(patch_pos_hw)
+        wi, wp = self._i32(window_index)
+        cw, cwp = self._i32(cu_window_seqlens)
+        cf, cfp = self._i32(cu_seqlens)
+        assert pos.shape == (n, 2) and wi.shape == (n // 4,), (pos.shape, wi.shape)
+        out = np.empty((n // 4, self.vlm_dims()["hidden"]), np.float32) if want_embeds else None
+        self._ck(self.lib.fe_vlm_encode_images(self.h, pv.ctypes.data_as(_f32p), n, pp, wp, cwp, len(cw) - 1, cfp, len(cf) - 1,
+                                               out.ctypes.data_as(_f32p) if want_embeds else None))
+        return out
+
     def vlm_dims(self):
         d = (C.c_int * 8)()
         self._ck(self.lib.fe_vlm_dims(self.h, d))
@@ -545,8 +570,10 @@ class Engine:
         a = np.ascontiguousarray(a, dtype=np.int32)
         return a, a.ctypes.data_as(C.POINTER(C.c_int32))
 
-    def vlm_prefill(self, tokens, position_ids=None, max_seq=None, want_logits=False):
+    def vlm_prefill(self, tokens, position_ids=None, max_seq=None, want_logits=False, image_rows=None):
         """tokens int [n_seq, len]; position_ids int [3, n_seq, len] (None: text-only positions 0..len-1 on all three axes).
+        image_rows: flat row indices (sequence * len + position) of the <|image_pad|> tokens, in order - they take the embeddings of
+        the last vlm_encode_images.
         -> next token ids [n_seq] (greedy) and, with want_logits, the bf16 logits widened to float32 [n_seq, vocab]."""
         tok, tp = self._i32(tokens)
         n, L = tok.shape
@@ -556,8 +583,13 @@ class Engine:
         assert pos.shape == (3, n, L), pos.shape
         nxt = np.empty(n, np.int32)
         lg = np.empty((n, self.vlm_dims()["vocab"]), np.float32) if want_logits else None
-        self._ck(self.lib.fe_vlm_prefill(self.h, tp, pp, n, L, int(max_seq or min(8192, L + 256)), nxt.ctypes.data_as(C.POINTER(C.c_int32)),
-                                         lg.ctypes.data_as(_f32p) if want_logits else None))
+        if image_rows is not None:
+            ir, irp = self._i32(image_rows)
+            self._ck(self.lib.fe_vlm_prefill_images(self.h, tp, pp, n, L, int(max_seq or min(8192, L + 256)), irp, int(ir.size),
+                                                    nxt.ctypes.data_as(C.POINTER(C.c_int32)), lg.ctypes.data_as(_f32p) if want_logits else None))
+        else:
+            self._ck(self.lib.fe_vlm_prefill(self.h, tp, pp, n, L, int(max_seq or min(8192, L + 256)), nxt.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             lg.ctypes.data_as(_f32p) if want_logits else None))
         return (nxt, lg) if want_logits else nxt
 
     def vlm_decode_step(self, tokens, position_ids, want_logits=False):
@@ -571,7 +603,7 @@ class Engine:
         self._ck(self.lib.fe_vlm_decode_step(self.h, tp, pp, n, nxt.ctypes.data_as(C.POINTER(C.c_int32)), lg.ctypes.data_as(_f32p) if want_logits else None))
         return (nxt, lg) if want_logits else nxt
 
-    def vlm_generate(self, tokens, max_new_tokens, position_ids=None, eos_token_ids=(), want_logits=False, forced_tokens=None):
+    def vlm_generate(self, tokens, max_new_tokens, position_ids=None, eos_token_ids=(), want_logits=False, forced_tokens=None, image_rows=None):
         """Greedy generation (`generate(..., do_sample=False)`, models/vlm_tagger.py:255-259): prefill + max_new_tokens - 1 decode
         steps for all sequences in lockstep; a sequence that emitted an EOS id keeps receiving that id (what generate's padding does).
         New positions continue from max(position_ids) + 1 per sequence. forced_tokens [n_seq, max_new_tokens]: teacher forcing - the
@@ -584,7 +616,7 @@ class Engine:
         nxt_pos = position_ids.max(axis=(0, 2)) + 1            # [n_seq]
         if not want_logits and forced_tokens is None:
             # the product path: prefill, then every decode step on the device (fe_vlm_generate: captured graph, no host round trips)
-            first = self.vlm_prefill(tok, position_ids, max_seq=min(8192, L + max_new_tokens))
+            first = self.vlm_prefill(tok, position_ids, max_seq=min(8192, L + max_new_tokens), image_rows=image_rows)
             out = np.empty((n, max_new_tokens), np.int32)
             out[:, 0] = first
             if max_new_tokens > 1:
@@ -601,7 +633,7 @@ class Engine:
             return out
         out = np.zeros((n, max_new_tokens), np.int32)
         logits = []
-        r = self.vlm_prefill(tok, position_ids, max_seq=min(8192, L + max_new_tokens), want_logits=want_logits)
+        r = self.vlm_prefill(tok, position_ids, max_seq=min(8192, L + max_new_tokens), want_logits=want_logits, image_rows=image_rows)
         cur = r[0] if want_logits else r
         done = np.zeros(n, bool)
         eos = set(int(e) for e in eos_token_ids)

@@ -1244,6 +1244,56 @@ int fe_tag_similarities(fe_ctx* ctx, const float* emb, int n, const float* text,
 }
 
 // ---- VLM tagger: text decoder of Qwen2.5-VL (models/vlm_tagger.py:163-184 load, :250-259 / :355-360 greedy generate) ----------------
+int fe_vlm_vision_configure(fe_ctx* ctx, int n_heads, const int* fullatt_block_indexes, int n_fullatt) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(n_heads > 0 && n_fullatt >= 0 && n_fullatt <= 8 && (n_fullatt == 0 || fullatt_block_indexes), "vlm_vision_configure: bad arguments (at most 8 full-attention blocks)");
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  VlmConfig& g = ctx->c.vlm_cfg;
+  g.vis_heads = n_heads; g.n_fullatt = n_fullatt;
+  for (int i = 0; i < n_fullatt; ++i) g.fullatt[i] = fullatt_block_indexes[i];
+  FE_API_END(ctx)
+}
+int fe_vlm_encode_images(fe_ctx* ctx, const float* pixel_values, int n_patches, const int32_t* patch_pos_hw, const int32_t* window_index, const int32_t* cu_window_seqlens,
+                         int n_windows, const int32_t* cu_seqlens, int n_images, float* embeds) {
+  FE_API_BEGIN(ctx)
+  if (!ctx->c.vlm || !ctx->c.vlm->vis.present) { ctx->c.err = "vlm vision tower not loaded (checkpoint had no model.visual.* tensors)"; return FE_ERR_NOT_LOADED; }
+  Ctx& C = ctx->c;
+  VlmModel& m = *C.vlm;
+  FE_CHECK(pixel_values && patch_pos_hw && window_index && cu_window_seqlens && cu_seqlens && n_patches > 0 && n_patches % 4 == 0 && n_windows > 0 && n_images > 0,
+           "bad arguments");
+  FE_CHECK(cu_window_seqlens[0] == 0 && cu_window_seqlens[n_windows] == n_patches && cu_seqlens[0] == 0 && cu_seqlens[n_images] == n_patches, "segment bounds must cover the patches");
+  int max_win = 0, max_full = 0;
+  for (int i = 0; i < n_windows; ++i) { FE_CHECK(cu_window_seqlens[i + 1] > cu_window_seqlens[i], "empty window segment"); max_win = std::max(max_win, cu_window_seqlens[i + 1] - cu_window_seqlens[i]); }
+  for (int i = 0; i < n_images; ++i) { FE_CHECK(cu_seqlens[i + 1] > cu_seqlens[i], "empty image segment"); max_full = std::max(max_full, cu_seqlens[i + 1] - cu_seqlens[i]); }
+  for (int i = 0; i < n_patches / 4; ++i) FE_CHECK(window_index[i] >= 0 && window_index[i] < n_patches / 4, "window_index out of range");
+  const int rows = n_patches / 4;
+  if (rows > m.img_cap) {
+    if (m.img_embeds) (void)hipFree(m.img_embeds);
+    m.img_embeds = nullptr; m.img_cap = 0;
+    FE_HIP(hipMalloc((void**)&m.img_embeds, (size_t)rows * m.hidden * sizeof(bf16)));
+    m.img_cap = rows;
+  }
+  C.arena.reset();
+  float* d_pv = (float*)C.arena.alloc((size_t)n_patches * m.vis.patch_dim * sizeof(float));
+  int* d_pos = (int*)C.arena.alloc((size_t)n_patches * 2 * sizeof(int));
+  int* d_widx = (int*)C.arena.alloc((size_t)rows * sizeof(int));
+  int* d_cw = (int*)C.arena.alloc((size_t)(n_windows + 1) * sizeof(int));
+  int* d_cf = (int*)C.arena.alloc((size_t)(n_images + 1) * sizeof(int));
+  FE_HIP(hipMemcpyAsync(d_pv, pixel_values, (size_t)n_patches * m.vis.patch_dim * sizeof(float), hipMemcpyHostToDevice, C.stream));
+  FE_HIP(hipMemcpyAsync(d_pos, patch_pos_hw, (size_t)n_patches * 2 * sizeof(int), hipMemcpyHostToDevice, C.stream));
+  FE_HIP(hipMemcpyAsync(d_widx, window_index, (size_t)rows * sizeof(int), hipMemcpyHostToDevice, C.stream));
+  FE_HIP(hipMemcpyAsync(d_cw, cu_window_seqlens, (size_t)(n_windows + 1) * sizeof(int), hipMemcpyHostToDevice, C.stream));
+  FE_HIP(hipMemcpyAsync(d_cf, cu_seqlens, (size_t)(n_images + 1) * sizeof(int), hipMemcpyHostToDevice, C.stream));
+  vlm_vision_forward(C, m, d_pv, n_patches, d_pos, d_widx, d_cw, n_windows, max_win, d_cf, n_images, max_full, m.img_embeds);
+  m.img_rows = rows;
+  if (embeds) {
+    float* d_f = (float*)C.arena.alloc((size_t)rows * m.hidden * sizeof(float));
+    launch_convert((const bf16*)m.img_embeds, d_f, (size_t)rows * m.hidden, C.stream);
+    FE_HIP(hipMemcpyAsync(embeds, d_f, (size_t)rows * m.hidden * sizeof(float), hipMemcpyDeviceToHost, C.stream));
+  }
+  FE_HIP(hipStreamSynchronize(C.stream));
+  FE_API_END(ctx)
+}
 int fe_vlm_configure(fe_ctx* ctx, int n_heads, int n_kv_heads, int head_dim, float rope_theta, float rms_eps, const int* mrope_section) {
   FE_API_BEGIN(ctx)
   FE_CHECK(n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0 && head_dim == 128 && rope_theta > 0.f && rms_eps > 0.f && mrope_section,
@@ -1265,7 +1315,8 @@ int fe_vlm_dims(fe_ctx* ctx, int* dims) {
 }
 extern "C++" {
 // tokens (+ optional replacement rows for image tokens) -> embeddings -> decoder -> next tokens; shared by prefill and decode
-static void vlm_step(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int len, int32_t* next_tokens, float* logits) {
+static void vlm_step(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int len, int32_t* next_tokens, float* logits,
+                     const int32_t* image_rows = nullptr, int n_image_rows = 0) {
   Ctx& C = ctx->c;
   VlmModel& m = *C.vlm;
   const int rows = n_seq * len;
@@ -1278,6 +1329,11 @@ static void vlm_step(fe_ctx* ctx, const int32_t* tokens, const int32_t* position
   FE_HIP(hipMemcpyAsync(d_tok, tokens, (size_t)rows * sizeof(int), hipMemcpyHostToDevice, C.stream));
   FE_HIP(hipMemcpyAsync(d_pos, position_ids, (size_t)3 * rows * sizeof(int), hipMemcpyHostToDevice, C.stream));
   vlm_embed(C, m, d_tok, rows, x);
+  if (n_image_rows > 0) {      // inputs_embeds.masked_scatter(image_mask, image_embeds): the merged image embeddings replace the placeholder rows, in order
+    int* d_idx = (int*)C.arena.alloc((size_t)n_image_rows * sizeof(int));
+    FE_HIP(hipMemcpyAsync(d_idx, image_rows, (size_t)n_image_rows * sizeof(int), hipMemcpyHostToDevice, C.stream));
+    vlm_put_rows(C, x, m.img_embeds, d_idx, n_image_rows, m.hidden);
+  }
   vlm_forward(C, m, x, d_pos, n_seq, len, d_next, d_logits);
   FE_HIP(hipMemcpyAsync(next_tokens, d_next, (size_t)n_seq * sizeof(int), hipMemcpyDeviceToHost, C.stream));
   if (logits) FE_HIP(hipMemcpyAsync(logits, d_logits, (size_t)n_seq * m.vocab * sizeof(float), hipMemcpyDeviceToHost, C.stream));
@@ -1291,6 +1347,20 @@ int fe_vlm_prefill(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_i
   ctx->c.vlm->reserve_cache(n_seq, max_seq);
   ctx->c.vlm->cur_len = 0;
   vlm_step(ctx, tokens, position_ids, n_seq, len, next_tokens, logits);
+  FE_API_END(ctx)
+}
+int fe_vlm_prefill_images(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int len, int max_seq, const int32_t* image_rows, int n_image_rows,
+                          int32_t* next_tokens, float* logits) {
+  FE_API_BEGIN(ctx)
+  if (!ctx->c.vlm) { ctx->c.err = "vlm weights not loaded"; return FE_ERR_NOT_LOADED; }
+  VlmModel& m = *ctx->c.vlm;
+  FE_CHECK(tokens && position_ids && next_tokens && n_seq > 0 && len > 0 && max_seq >= len && max_seq <= 8192, "bad arguments (max_seq <= 8192)");
+  FE_CHECK(n_image_rows == 0 || (image_rows && n_image_rows == m.img_rows), "prefill_images: %d placeholder rows but the last fe_vlm_encode_images left %d embeddings",
+           n_image_rows, m.img_rows);
+  for (int i = 0; i < n_image_rows; ++i) FE_CHECK(image_rows[i] >= 0 && image_rows[i] < n_seq * len, "prefill_images: row index out of range");
+  m.reserve_cache(n_seq, max_seq);
+  m.cur_len = 0;
+  vlm_step(ctx, tokens, position_ids, n_seq, len, next_tokens, logits, image_rows, n_image_rows);
   FE_API_END(ctx)
 }
 int fe_vlm_generate(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int n_steps, int32_t* out_tokens) {

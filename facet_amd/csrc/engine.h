@@ -191,7 +191,10 @@ class Graph;   // onnx_graph.h
 struct GraphSlot;
 
 // geometry the checkpoint's tensor shapes do not determine (transformers Qwen2_5_VLTextConfig): defaults = Qwen2.5-VL-7B-Instruct
-struct VlmConfig { int n_heads = 28, n_kv_heads = 4, head_dim = 128; float rope_theta = 1e6f, rms_eps = 1e-6f; int mrope[3] = {16, 24, 24}; };
+struct VlmConfig {
+  int n_heads = 28, n_kv_heads = 4, head_dim = 128; float rope_theta = 1e6f, rms_eps = 1e-6f; int mrope[3] = {16, 24, 24};
+  int vis_heads = 16, fullatt[8] = {7, 15, 23, 31, 0, 0, 0, 0}, n_fullatt = 4;      // vision tower (Qwen2_5_VLVisionConfig)
+};
 
 struct OpTiming { std::string name; double flops; double bytes; float ms; };
 
@@ -324,6 +327,15 @@ void l2_normalize(Ctx& c, const float* x, float* y, int rows, int d);
 
 // ---- VLM tagger text decoder (transformers Qwen2_5_VLForConditionalGeneration; reference models/vlm_tagger.py) - model_vlm.hip ----------
 struct VlmLayerW { ConvW qkv, o, gate, up, down; bf16* ln1 = nullptr; bf16* ln2 = nullptr; };
+struct VlmVisionBlockW { ConvW qkv, proj, gate, up, down; bf16* n1 = nullptr; bf16* n2 = nullptr; };
+struct VlmVisionW {      // model.visual.* (model_vlm_vision.hip)
+  bool present = false;
+  ConvW patch, m0, m2;
+  std::vector<VlmVisionBlockW> blocks;
+  bf16* ln_q = nullptr; float* inv_freq = nullptr;
+  int hidden = 0, heads = 0, inter = 0, out_hidden = 0, patch_dim = 0;
+  std::vector<int> fullatt;
+};
 struct VlmModel {
   DeviceWeights dw;
   VlmConfig cfg;
@@ -331,14 +343,24 @@ struct VlmModel {
   ConvW lm_head;
   std::vector<VlmLayerW> layers;
   int vocab = 0, hidden = 0, inter = 0;
+  VlmVisionW vis;
+  bf16* img_embeds = nullptr; int img_rows = 0, img_cap = 0;      // merged image embeddings of the last fe_vlm_encode_images (device)
   // contiguous KV cache: per layer [n_seq][n_kv_heads][max_seq][128] keys (rotated) and values
   std::vector<bf16*> kcache, vcache;
   int cache_B = 0, max_seq = 0, cur_len = 0;
   void reserve_cache(int B, int max_seq);
   void release_cache();
-  ~VlmModel() { release_cache(); }
+  ~VlmModel() { release_cache(); if (img_embeds) (void)hipFree(img_embeds); }
 };
 void build_vlm(VlmModel& m, const WeightStore& ws, const VlmConfig& cfg);
+void build_vlm_vision(VlmModel& m, const WeightStore& ws);
+void vlm_vision_forward(Ctx& c, VlmModel& m, const float* pv, int N, const int* pos, const int* widx, const int* cu_win, int n_win, int max_win,
+                        const int* cu_full, int n_full, int max_full, bf16* out);
+// row kernels shared by the decoder and the vision tower (model_vlm.hip)
+void vlm_rmsnorm(Ctx& c, const bf16* x, int ldx, const bf16* w, bf16* y, int ldy, int rows, int d, float eps);
+void vlm_add(Ctx& c, bf16* x, const bf16* y, size_t n);
+void vlm_silu_mul(Ctx& c, const bf16* g, const bf16* u, bf16* h, size_t n);
+void vlm_put_rows(Ctx& c, bf16* x, const bf16* rows, const int* index, int n, int d);
 void vlm_embed(Ctx& c, const VlmModel& m, const int* tok_dev, int rows, bf16* x);
 void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int* next_dev, float* logits_dev, const int* len_dev = nullptr);
 void vlm_decode_steps(Ctx& c, VlmModel& m, int* tok_dev, int* pos_dev, int B, int n_steps, int* out_dev);

@@ -323,6 +323,15 @@ __global__ __launch_bounds__(256) void vlm_attn_decode_kernel(const bf16* __rest
   if (t < 128) o[((size_t)b * nh + head) * 128 + t] = (bf16)(part[t] + part[128 + t] + part[256 + t] + part[384 + t]);
 }
 
+// x[index[i]][:] = rows[i][:]   (image embeddings into the rows of their <|image_pad|> tokens)
+__global__ void vlm_put_rows_kernel(bf16* __restrict__ x, const bf16* __restrict__ rows, const int* __restrict__ index, int n, int d) {
+  const size_t total = (size_t)n * (d / 8);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (d / 8)), c = (int)(i % (d / 8)) * 8;
+    *reinterpret_cast<uint4*>(x + (size_t)index[r] * d + c) = *reinterpret_cast<const uint4*>(rows + (size_t)r * d + c);
+  }
+}
+
 // ---- decode GEMV: y[m][n] = sum_k x[m][k] w[n][k] (+ bias) for M <= 4 sequences - the shape of every projection of a decode step at the
 // reference's batch sizes (vlm_batch_size 2, models/vlm_tagger.py:76). Pure weight streaming: one wave per TWO output columns, 16-byte
 // loads (8 weights per lane and row), the M activation rows come from L1 / L2; fp32 accumulation, one rounding to bf16 (or fp32 out
@@ -477,6 +486,7 @@ void build_vlm(VlmModel& m, const WeightStore& ws, const VlmConfig& cfg) {
   std::vector<float> inv(64);
   for (int i = 0; i < 64; ++i) inv[i] = 1.0f / powf(cfg.rope_theta, (float)(2 * i) / 128.0f);
   m.inv_freq = m.dw.upload(inv);
+  build_vlm_vision(m, ws);      // model.visual.* when the checkpoint carries it
 }
 
 void VlmModel::reserve_cache(int B, int max_seq_) {
@@ -500,6 +510,23 @@ void VlmModel::release_cache() {
 }
 
 static inline int grid_n(size_t n, int per = 256) { size_t g = (n + per - 1) / per; return (int)(g > 65535 * 4 ? 65535 * 4 : (g ? g : 1)); }
+
+void vlm_rmsnorm(Ctx& c, const bf16* x, int ldx, const bf16* w, bf16* y, int ldy, int rows, int d, float eps) {
+  hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, x, ldx, w, y, ldy, rows, d, eps);
+  FE_HIP(hipGetLastError());
+}
+void vlm_add(Ctx& c, bf16* x, const bf16* y, size_t n) {
+  hipLaunchKernelGGL(vlm_add_kernel, dim3(grid_n(n / 4)), dim3(256), 0, c.stream, x, y, n / 4);
+  FE_HIP(hipGetLastError());
+}
+void vlm_silu_mul(Ctx& c, const bf16* g, const bf16* u, bf16* h, size_t n) {
+  hipLaunchKernelGGL(vlm_silu_mul_kernel, dim3(grid_n(n / 4)), dim3(256), 0, c.stream, g, u, h, n / 4);
+  FE_HIP(hipGetLastError());
+}
+void vlm_put_rows(Ctx& c, bf16* x, const bf16* rows, const int* index, int n, int d) {
+  hipLaunchKernelGGL(vlm_put_rows_kernel, dim3(grid_n((size_t)n * d / 8)), dim3(256), 0, c.stream, x, rows, index, n, d);
+  FE_HIP(hipGetLastError());
+}
 
 // x: [B*L][hidden] bf16 rows (token embeddings, image rows already in place), pos: device [3][B*L]. Appends L positions to the cache of
 // every sequence, leaves the next token of every sequence in next_dev [B] and (optionally) the bf16-rounded logits in logits_dev [B][vocab].

@@ -243,6 +243,30 @@ def qwen2_5_vl_text_spec(hidden=3584, layers=28, heads=28, kv_heads=4, inter=189
     return spec
 
 
+def qwen2_5_vl_vision_spec(hidden=1280, depth=32, inter=3420, out_hidden=3584, patch=14, temporal=2):
+    """Vision tower of Qwen2_5_VLForConditionalGeneration (`model.visual.*`): Conv3d patch embedding (no bias), `depth` blocks of
+    RMSNorm - fused qkv (+bias) - proj (+bias) - RMSNorm - SwiGLU MLP (+biases), the patch merger (RMSNorm, Linear(4 hidden, 4 hidden),
+    GELU, Linear(4 hidden, out_hidden)). Defaults = Qwen2.5-VL-7B-Instruct (16 heads of 80)."""
+    v = "model.visual."
+    spec = [(v + "patch_embed.proj.weight", (hidden, 3, temporal, patch, patch), "linear_nd")]
+    for i in range(depth):
+        b = f"{v}blocks.{i}"
+        spec.append((b + ".norm1.weight", (hidden,), "ln_w"))
+        spec.append((b + ".norm2.weight", (hidden,), "ln_w"))
+        _linear(spec, b + ".attn.qkv", 3 * hidden, hidden)
+        _linear(spec, b + ".attn.proj", hidden, hidden)
+        _linear(spec, b + ".mlp.gate_proj", inter, hidden)
+        _linear(spec, b + ".mlp.up_proj", inter, hidden)
+        _linear(spec, b + ".mlp.down_proj", hidden, inter)
+    spec.append((v + "merger.ln_q.weight", (hidden,), "ln_w"))
+    _linear(spec, v + "merger.mlp.0", 4 * hidden, 4 * hidden)
+    _linear(spec, v + "merger.mlp.2", out_hidden, 4 * hidden)
+    return spec
+
+
+# reduced vision tower of the parity tests: Qwen2.5-VL's head_dim 80, window attention with one full-attention block
+VLM_VISION_TINY = dict(hidden=160, depth=3, inter=320, out_hidden=512)
+
 # the reduced-depth configuration of the VLM parity tests (tests/golden/make_vlm_golden.py): Qwen2.5-VL's head_dim 128 and 2:1 grouped
 # KV heads at a size the CPU oracle generates from in seconds
 VLM_TINY = dict(hidden=512, layers=4, heads=4, kv_heads=2, inter=1408, vocab=2048)
@@ -250,6 +274,7 @@ VLM_TINY = dict(hidden=512, layers=4, heads=4, kv_heads=2, inter=1408, vocab=204
 SPECS = {
     "qwen2_5_vl_text": qwen2_5_vl_text_spec,
     "qwen2_5_vl_text_tiny": lambda: qwen2_5_vl_text_spec(**VLM_TINY),
+    "qwen2_5_vl_tiny": lambda: qwen2_5_vl_text_spec(**VLM_TINY) + qwen2_5_vl_vision_spec(**VLM_VISION_TINY),
     "topiq": topiq_spec,
     "resnet50": lambda: resnet_spec("semantic_model.", True, [3, 4, 6, 3]),
     "clip": clip_vit_spec,
@@ -277,6 +302,8 @@ def _draw(rng, shape, kind):
         return rng.uniform(0.6, 0.9, shape).astype(np.float32)
     if kind == "linear":
         return rng.standard_normal(shape, dtype=np.float32) * np.float32(1.0 / np.sqrt(shape[1]))
+    if kind == "linear_nd":      # a linear map stored with an N-d kernel (Conv3d patch embedding): fan-in = everything but the first axis
+        return rng.standard_normal(shape, dtype=np.float32) * np.float32(1.0 / np.sqrt(np.prod(shape[1:])))
     if kind == "proj":
         return rng.standard_normal(shape, dtype=np.float32) * np.float32(1.0 / np.sqrt(shape[0]))
     if kind == "bias":

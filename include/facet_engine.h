@@ -92,6 +92,24 @@ int fe_model_precision(fe_ctx* ctx, int model); /* enum fe_precision value of a 
  * ties, as torch.argmax) and, when `logits` is not NULL, those logits [n_seq][vocab]. fe_vlm_decode_step appends one token per
  * sequence (tokens [n_seq], position_ids [3][n_seq]). dims: vocab, hidden, layers, heads, kv_heads, intermediate, max_seq, cur_len. */
 int fe_vlm_configure(fe_ctx* ctx, int n_heads, int n_kv_heads, int head_dim, float rope_theta, float rms_eps, const int* mrope_section);
+/* Vision tower (slice 2; built when the FE_MODEL_VLM checkpoint carries model.visual.*): geometry the tensor shapes do not determine
+ * (defaults = Qwen2.5-VL-7B: 16 heads of 80, full attention in blocks 7 / 15 / 23 / 31, every other block inside 112-pixel windows), read
+ * by the NEXT fe_weights_commit(FE_MODEL_VLM).
+ * fe_vlm_encode_images = `model.visual(pixel_values, grid_thw).pooler_output` (what generate() runs on the processor's output,
+ * models/vlm_tagger.py:245-259): pixel_values [n_patches][1176] (the processor's flattened 3 x 2 x 14 x 14 patches, fp32), and the
+ * index arrays transformers.vision_utils derives from image_grid_thw (facet_amd/vlm_tagger.py restates them in numpy): patch_pos_hw
+ * [n_patches][2] = (row, column) of every patch IN WINDOW ORDER, window_index [n_patches / 4] = raster index of the 2x2 merge block at
+ * each window-order slot, cu_window_seqlens [n_windows + 1] and cu_seqlens [n_images + 1] = segment bounds (in patches, window order)
+ * of the windowed and the full-attention blocks. The merged embeddings [n_patches / 4][hidden] (raster order) stay on the device for
+ * the next fe_vlm_prefill_images and are also copied to `embeds` when it is not NULL (bf16 values widened to float).
+ * fe_vlm_prefill_images = fe_vlm_prefill whose rows image_rows[i] (flat index sequence * len + position, one per <|image_pad|> token, in
+ * order) take the i-th embedding instead of the token's (`inputs_embeds.masked_scatter(image_mask, image_embeds)`); position_ids are
+ * get_rope_index's (temporal / height / width ids of the image tokens). */
+int fe_vlm_vision_configure(fe_ctx* ctx, int n_heads, const int* fullatt_block_indexes, int n_fullatt);
+int fe_vlm_encode_images(fe_ctx* ctx, const float* pixel_values, int n_patches, const int32_t* patch_pos_hw, const int32_t* window_index,
+                         const int32_t* cu_window_seqlens, int n_windows, const int32_t* cu_seqlens, int n_images, float* embeds);
+int fe_vlm_prefill_images(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int len, int max_seq, const int32_t* image_rows,
+                          int n_image_rows, int32_t* next_tokens, float* logits);
 int fe_vlm_dims(fe_ctx* ctx, int* dims8);
 int fe_vlm_prefill(fe_ctx* ctx, const int32_t* tokens, const int32_t* position_ids, int n_seq, int len, int max_seq, int32_t* next_tokens,
                    float* logits);

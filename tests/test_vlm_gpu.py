@@ -155,3 +155,77 @@ def test_live_against_transformers_when_importable(vlm_engine, name, cfg, B, L, 
     print(f"[vlm live: {name}] max |logit diff| {diff.max():.4f} of scale {scale:.2f} (tol {tol:.4f}); argmax equal on "
           f"{int(((toks == ref_tok) & decisive).sum())} of {int(decisive.sum())} decisive steps")
     assert diff.max() <= tol and ((toks == ref_tok) | ~decisive).all()
+
+
+# ---- slice 2: the vision tower and prompts with images ---------------------------------------------------------------------------------
+GV = np.load(os.path.join(os.path.dirname(__file__), "golden", "vlm_vision_golden.npz"))
+
+
+def _planted_full(seed):
+    sd = synthetic_state_dict("qwen2_5_vl_tiny", seed)
+    perm = np.random.default_rng([seed, 77]).permutation(VLM_TINY["vocab"])
+    sd["lm_head.weight"] = (sd["model.language_model.embed_tokens.weight"][perm] / 16.0).astype(np.float32)
+    return sd
+
+
+def test_vision_tower_and_image_prompt_against_the_reference_class(vlm_engine):
+    """tests/golden/make_vlm_vision_golden.py: two images (10x12 and 6x6 patches: ragged windows, a one-window image) through
+    `model.visual` of the reference's class, and `generate` on a prompt that carries both. The merged image embeddings must agree within
+    0.0625 (|max| 2.7; transformers' own sdpa and eager paths differ by 0.031), the M-RoPE position ids and the index arrays exactly
+    (host restatements), the 16 greedy tokens exactly, first / last logits within 0.25."""
+    from facet_amd.vlm_tagger import vision_indices, rope_index
+    e = vlm_engine
+    e.vlm_vision_configure(int(GV["vis_heads"]), [int(v) for v in GV["fullatt"]])
+    e.load_weights(FE_MODEL_VLM, _planted_full(int(GV["seed_w"])))
+    grid = GV["grid_thw"]
+    n_patches = int((grid[:, 0] * grid[:, 1] * grid[:, 2]).sum())
+    pv = np.random.default_rng(int(GV["pixel_seed"])).normal(0, 1, (n_patches, 1176)).astype(np.float32)
+    idx = vision_indices(grid)
+    emb = e.vlm_encode_images(pv, idx["patch_pos_hw"], idx["window_index"], idx["cu_window_seqlens"], idx["cu_seqlens"])
+    err = np.abs(emb - GV["embeds"]).max()
+    print(f"[vlm vision] embeds {emb.shape}: max |diff| {err:.4f} (|max| {np.abs(GV['embeds']).max():.2f}, transformers sdpa-vs-eager {float(GV['attn_impl_spread_embeds']):.4f})")
+    assert emb.shape == GV["embeds"].shape and err <= 0.0625
+    ids = GV["input_ids"]
+    pos, nxt = rope_index(ids, grid, int(GV["image_token_id"]))
+    assert np.array_equal(pos, GV["position_ids"])
+    rows = np.flatnonzero(ids.reshape(-1) == int(GV["image_token_id"])).astype(np.int32)
+    toks, logits = e.vlm_generate(ids, GV["tokens"].shape[1], position_ids=pos, want_logits=True, image_rows=rows)
+    e0, e1 = np.abs(logits[:, 0] - GV["logits_step0"]).max(), np.abs(logits[:, -1] - GV["logits_last"]).max()
+    print(f"[vlm image prompt] tokens equal: {np.array_equal(toks, GV['tokens'])}; logits |diff| step 0 {e0:.4f}, last {e1:.4f} (transformers sdpa-vs-eager {float(GV['attn_impl_spread_logits']):.3f})")
+    assert np.array_equal(toks, GV["tokens"]) and e0 <= 0.25 and e1 <= 0.25
+    # the product path (device-resident decode loop) through the host mirror
+    from facet_amd.vlm_tagger import VLMTagger
+    t = VLMTagger({"model_path": "Qwen/Qwen2.5-VL-7B-Instruct", "max_new_tokens": GV["tokens"].shape[1]}, engine=e)
+    t.model = e
+    assert np.array_equal(t.generate_with_images(ids, pv, grid, int(GV["image_token_id"])), GV["tokens"])
+
+
+def test_vision_tower_live_at_the_7b_width_when_transformers_imports(vlm_engine):
+    """One block pair at Qwen2.5-VL-7B's vision width (1280 = 16 heads of 80, intermediate 3420, merger 5120 -> 512) on a 34 x 46-patch
+    image (ragged windows on both axes, a 1564-patch full-attention segment) against transformers' vision class itself."""
+    torch = pytest.importorskip("torch")
+    pytest.importorskip("transformers")
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VisionTransformerPretrainedModel
+    from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLVisionConfig
+    from facet_amd.weights import qwen2_5_vl_vision_spec
+    from facet_amd.vlm_tagger import vision_indices
+    vc = dict(hidden=1280, depth=2, inter=3420, out_hidden=512)
+    sd = synthetic_state_dict(None, 23, spec=qwen2_5_vl_text_spec(**VLM_TINY) + qwen2_5_vl_vision_spec(**vc))
+    e = vlm_engine
+    e.vlm_vision_configure(16, [1])
+    e.load_weights(FE_MODEL_VLM, sd)
+    cfg = Qwen2_5_VLVisionConfig(depth=2, hidden_size=1280, intermediate_size=3420, num_heads=16, out_hidden_size=512, patch_size=14, spatial_merge_size=2,
+                                 temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1])
+    m = Qwen2_5_VisionTransformerPretrainedModel(cfg).eval()
+    missing, unexpected = m.load_state_dict({k[len("model.visual."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("model.visual.")}, strict=False)
+    assert not missing and not unexpected
+    m = m.to(torch.bfloat16)
+    grid = np.array([[1, 34, 46]], np.int64)
+    pv = np.random.default_rng(3).normal(0, 1, (34 * 46, 1176)).astype(np.float32)
+    with torch.no_grad():
+        ref = m(torch.from_numpy(pv).to(torch.bfloat16), grid_thw=torch.from_numpy(grid)).pooler_output.float().numpy()
+    idx = vision_indices(grid)
+    emb = e.vlm_encode_images(pv, idx["patch_pos_hw"], idx["window_index"], idx["cu_window_seqlens"], idx["cu_seqlens"])
+    scale = np.abs(ref).max()
+    print(f"[vlm vision live, 7B width] max |diff| {np.abs(emb - ref).max():.4f} of |max| {scale:.2f}")
+    assert np.abs(emb - ref).max() <= scale * 2.0 ** -5

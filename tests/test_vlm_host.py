@@ -52,3 +52,35 @@ def test_family_detection_and_batch_size():
     assert VLMTagger({"model_path": "x", "vlm_batch_size": 7}).batch_size == G["qwen3_family"]["custom_batch"]
     with pytest.raises(RuntimeError):
         VLMTagger({"model_path": "Qwen/Qwen2.5-VL-7B-Instruct"}).generate_ids([[1, 2, 3]])      # not loaded: fails loudly
+
+
+def test_rope_index_and_vision_indices_match_the_reference():
+    """The index arithmetic the host mirror restates from transformers (M-RoPE position ids of a prompt with two images; window order and
+    segment bounds of the vision tower) against what the reference's class computed (tests/golden/make_vlm_vision_golden.py) and, when
+    transformers is importable, against its utilities for more grids."""
+    import numpy as np
+    from facet_amd.vlm_tagger import vision_indices, rope_index
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vlm_vision_golden.npz"))
+    pos, nxt = rope_index(g["input_ids"], g["grid_thw"], int(g["image_token_id"]))
+    assert np.array_equal(pos, g["position_ids"]) and nxt.tolist() == [int(g["position_ids"].max()) + 1]
+    idx = vision_indices(g["grid_thw"])
+    n = int((g["grid_thw"][:, 0] * g["grid_thw"][:, 1] * g["grid_thw"][:, 2]).sum())
+    assert idx["patch_pos_hw"].shape == (n, 2) and sorted(idx["window_index"].tolist()) == list(range(n // 4))
+    assert idx["cu_window_seqlens"][0] == 0 and idx["cu_window_seqlens"][-1] == n and (np.diff(idx["cu_window_seqlens"]) > 0).all()
+    assert idx["cu_seqlens"].tolist() == [0, 120, 156]
+    with pytest.raises(ValueError):
+        rope_index(g["input_ids"][:, :20], g["grid_thw"], int(g["image_token_id"]))      # a truncated placeholder run
+    try:
+        import torch
+        import transformers.vision_utils as vu
+    except Exception:
+        return
+    for grid in ([[1, 16, 16]], [[1, 8, 24], [1, 22, 18], [1, 2, 2]], [[1, 34, 46]]):
+        gt = torch.tensor(grid)
+        got = vision_indices(grid)
+        wi, cw = vu.get_vision_window_index(gt, 2, 112, 14)
+        p = vu.get_vision_position_ids(gt, 2)
+        k = p.shape[0]
+        assert np.array_equal(got["window_index"], wi.numpy()) and np.array_equal(got["cu_window_seqlens"], cw.numpy())
+        assert np.array_equal(got["patch_pos_hw"], p.reshape(k // 4, 4, 2)[wi].reshape(k, 2).numpy())
+        assert np.array_equal(got["cu_seqlens"], vu.get_vision_cu_seqlens(gt).numpy())
