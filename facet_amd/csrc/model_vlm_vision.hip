@@ -278,8 +278,15 @@ void vlm_vision_forward(Ctx& c, VlmModel& m, const float* pv, int N, const int* 
   bf16* kr = c.arena.array<bf16>((size_t)N * d);
   bf16* ao = c.arena.array<bf16>((size_t)N * d);
   bf16* br = c.arena.array<bf16>((size_t)N * d);
-  bf16* gg = c.arena.array<bf16>((size_t)N * v.inter);
-  bf16* uu = c.arena.array<bf16>((size_t)N * v.inter);
+  // the MLP width (3420 at the 7B geometry) is not a multiple of 8: rows are padded to the 8 columns the 2-byte GEMM reads per chunk,
+  // the padding zeroed once (silu(0) * 0 = 0 keeps it zero; the packed down_proj weights are zero there too)
+  const int ip = (v.inter + 7) & ~7;
+  bf16* gg = c.arena.array<bf16>((size_t)N * ip);
+  bf16* uu = c.arena.array<bf16>((size_t)N * ip);
+  if (ip != v.inter) {
+    FE_HIP(hipMemsetAsync(gg, 0, (size_t)N * ip * sizeof(bf16), c.stream));
+    FE_HIP(hipMemsetAsync(uu, 0, (size_t)N * ip * sizeof(bf16), c.stream));
+  }
   launch_convert(pv, pvh, (size_t)N * v.patch_dim, c.stream);      // pixel_values.to(bfloat16), as the patch embedding does
   vis_linear(c, v.patch, pvh, v.patch_dim, N, h0, d);
   hipLaunchKernelGGL(vlm_vis_gather_kernel, dim3(vgrid((size_t)N * d / 8)), dim3(256), 0, c.stream, (const bf16*)h0, x, widx, N / 4, 4, d, 0);
@@ -299,10 +306,10 @@ void vlm_vision_forward(Ctx& c, VlmModel& m, const float* pv, int N, const int* 
     vis_linear(c, w.proj, ao, d, N, br, d);
     vlm_add(c, x, br, (size_t)N * d);
     vlm_rmsnorm(c, x, d, w.n2, n, d, N, d, 1e-6f);
-    vis_linear(c, w.gate, n, d, N, gg, v.inter);
-    vis_linear(c, w.up, n, d, N, uu, v.inter);
-    vlm_silu_mul(c, gg, uu, gg, (size_t)N * v.inter);
-    vis_linear(c, w.down, gg, v.inter, N, br, d);
+    vis_linear(c, w.gate, n, d, N, gg, ip);
+    vis_linear(c, w.up, n, d, N, uu, ip);
+    vlm_silu_mul(c, gg, uu, gg, (size_t)N * ip);
+    vis_linear(c, w.down, gg, ip, N, br, d);
     vlm_add(c, x, br, (size_t)N * d);
   }
   // merger: RMSNorm per patch row, four consecutive rows = one merged row, Linear - GELU - Linear, then raster order

@@ -19,10 +19,15 @@ ap.add_argument("--layers", type=int, default=8)
 ap.add_argument("--prompt", type=int, default=512)
 ap.add_argument("--new", type=int, default=16)
 ap.add_argument("--batches", default="1,8,32")
+ap.add_argument("--vision", type=int, default=0, help="also time the vision tower: this many images of 1036x1036 pixels (74x74 patches) per call, full depth 32")
 a = ap.parse_args()
 H, NH, NKV, INTER, V = 3584, 28, 4, 18944, 152064
 t0 = time.time()
-sd = synthetic_state_dict(None, 3, spec=qwen2_5_vl_text_spec(hidden=H, layers=a.layers, heads=NH, kv_heads=NKV, inter=INTER, vocab=V))
+from facet_amd.weights import qwen2_5_vl_vision_spec
+spec = qwen2_5_vl_text_spec(hidden=H, layers=a.layers, heads=NH, kv_heads=NKV, inter=INTER, vocab=V)
+if a.vision:
+    spec = spec + qwen2_5_vl_vision_spec()      # 32 blocks of 1280 (16 heads of 80), intermediate 3420, merger to 3584
+sd = synthetic_state_dict(None, 3, spec=spec)
 print(f"weights drawn in {time.time() - t0:.0f} s", flush=True)
 e = Engine(0, arena_bytes=40 << 30)
 e.vlm_configure(NH, NKV, 128, 1e6, 1e-6, (16, 24, 24))
@@ -30,6 +35,18 @@ t0 = time.time()
 e.load_weights(FE_MODEL_VLM, sd)
 del sd
 print(f"committed in {time.time() - t0:.0f} s", flush=True)
+if a.vision:
+    from facet_amd.vlm_tagger import vision_indices
+    g = [[1, 74, 74]] * a.vision
+    idx = vision_indices(g)
+    n = 74 * 74 * a.vision
+    pv = np.random.default_rng(0).normal(0, 1, (n, 1176)).astype(np.float32)
+    e.vlm_encode_images(pv, idx["patch_pos_hw"], idx["window_index"], idx["cu_window_seqlens"], idx["cu_seqlens"], want_embeds=False)
+    e.flops_reset(); e.timer_start()
+    e.vlm_encode_images(pv, idx["patch_pos_hw"], idx["window_index"], idx["cu_window_seqlens"], idx["cu_seqlens"], want_embeds=False)
+    ms = e.timer_stop()
+    print(f"vision tower: {a.vision} images of 74x74 patches ({n // 4 // a.vision} image tokens each) in {ms:.2f} ms = {a.vision / ms * 1e3:.1f} images/s, "
+          f"{e.flops() / ms / 1e9:.1f} TFLOP/s (projections; host patches uploaded inside the call)", flush=True)
 layer_params = H * (NH + 2 * NKV) * 128 + NH * 128 * H + 3 * H * INTER
 head_params = V * H
 for B in [int(b) for b in a.batches.split(",")]:
