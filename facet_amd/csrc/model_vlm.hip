@@ -411,9 +411,86 @@ static void vlm_gemv(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, TO* 
   FE_HIP(hipGetLastError());
   c.flops_accum += 2.0 * M * (double)w.Cin * w.Cout;
 }
-// y = x W^T (+ b) in bf16 for any row count: the streaming GEMV for up to 4 rows, the shared layer wrapper above that
+// ---- decode GEMM for 5 .. 32 sequences: the weight rows are the A operand of v_mfma_f32_32x32x16_bf16 (32 output columns per wave),
+// the activation rows the B operand (batch rows padded to 32 with zeros), K split over the workgroups of grid.y and the four waves of
+// each; every weight byte is read once per step. Inside a 64-element block of K lane (r, h) owns elements 32 h .. 32 h + 31 of its row
+// (64 contiguous bytes = four 16-byte loads = the fragments of four matrix instructions; the contraction order is free as long as both
+// operands use it). Partial sums [split][M][N] in fp32, added in a fixed order by the finishing kernel (no atomics: the same token ids
+// on every run).
+__global__ __launch_bounds__(256) void vlm_gemm32_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w, int ldw, float* __restrict__ part, int M, int N,
+                                                         int K, int kblocks_per_wg) {
+  __shared__ float red[3][32 * 33];
+  const bf16* const tag = nullptr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 32;
+  const int nr = n0 + r < N ? n0 + r : N - 1;               // rows past N are computed on a valid row and dropped
+  const bf16* wr = w + (size_t)nr * ldw + 32 * h;
+  const bf16* xr = x + (size_t)(r < M ? r : 0) * ldx + 32 * h;
+  const bool xok = r < M;
+  fe_f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const int kb0 = blockIdx.y * kblocks_per_wg, kb1 = min(kb0 + kblocks_per_wg, K / 64);
+  for (int kb = kb0 + wave; kb < kb1; kb += 4) {
+    const int k = kb * 64;
+    v4u a[4];
+    uint4 b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(wr + k + 8 * s));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[s] = xok ? *reinterpret_cast<const uint4*>(xr + k + 8 * s) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = fe_mfma16(tag, __builtin_bit_cast(fe_v4f, a[s]), __builtin_bit_cast(fe_v4f, b[s]), acc);
+  }
+  // acc: lane (r, h) holds column m = r (batch row) of the 32 x 32 tile, rows n = (e & 3) + 8 (e >> 2) + 4 h
+  if (wave > 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave - 1][((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = acc[e];
+  }
+  __syncthreads();
+  if (wave == 0 && r < M) {
+    float* out = part + ((size_t)blockIdx.y * M + r) * N + n0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int nn = (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (n0 + nn < N) out[nn] = (acc[e] + red[0][nn * 33 + r]) + (red[1][nn * 33 + r] + red[2][nn * 33 + r]);
+    }
+  }
+}
+template <class TO>
+__global__ void vlm_gemm32_finish_kernel(const float* __restrict__ part, int splits, int M, int N, const float* __restrict__ bias, TO* __restrict__ y, int ldy) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * N) return;
+  const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+  float v = bias ? bias[n] : 0.f;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += part[((size_t)k * M + m) * N + n];
+  stf(y + (size_t)m * ldy + n, s + v);
+}
+template <class TO>
+static void vlm_gemm32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, TO* y, int ldy) {
+  const int K = w.CinPadH, N = w.Cout;
+  FE_CHECK(w.wh && w.hprec == PREC_BF16 && !w.scale && K % 64 == 0 && w.KpH % 8 == 0 && ldx % 8 == 0 && M >= 1 && M <= 32, "vlm_gemm32: unsupported layer");
+  const int ntiles = (N + 31) / 32, kblocks = K / 64;
+  int splits = std::max(1, std::min(kblocks / 4, (2048 + ntiles * 4 - 1) / (ntiles * 4)));      // enough waves to stream from all of HBM: >= ~2048
+  const int per = (kblocks + splits - 1) / splits;
+  splits = (kblocks + per - 1) / per;
+  const size_t mark = c.arena.mark();
+  float* part = c.arena.array<float>((size_t)splits * M * N);
+  hipLaunchKernelGGL(vlm_gemm32_kernel, dim3(ntiles, splits), dim3(256), 0, c.stream, x, ldx, (const bf16*)w.wh, w.KpH, part, M, N, K, per);
+  hipLaunchKernelGGL((vlm_gemm32_finish_kernel<TO>), dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, c.stream, (const float*)part, splits, M, N,
+                     (const float*)w.shift, y, ldy);
+  FE_HIP(hipGetLastError());
+  c.arena.rewind(mark);
+  c.flops_accum += 2.0 * M * (double)w.Cin * N; c.flops_half += 2.0 * M * (double)w.Cin * N;
+}
+// y = x W^T (+ b) in bf16 for any row count: the streaming GEMV for up to 4 rows, the weight-streaming matrix-core GEMM up to 32, the
+// shared layer wrapper above that
 static void vlm_linear(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16* y, int ldy) {
+  static const bool no32 = getenv("FE_VLM_NO_GEMM32") != nullptr;      // A/B hook
   if (M <= 4) vlm_gemv(c, w, x, ldx, M, y, ldy);
+  else if (M <= 32 && w.CinPadH % 64 == 0 && !no32) vlm_gemm32(c, w, x, ldx, M, y, ldy);
   else linear_forward(c, w, x, ldx, M, y, ldy, ACT_NONE);
 }
 
@@ -579,6 +656,7 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
   hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)B * 64)), dim3(256), 0, c.stream, (const bf16*)last, d, (const bf16*)m.norm, lastn, d, B, d, g.rms_eps);
   float* lg = logits_dev ? logits_dev : c.arena.array<float>((size_t)B * m.vocab);
   if (B <= 4) vlm_gemv(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab);
+  else if (B <= 32 && d % 64 == 0) vlm_gemm32(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab);
   else linear_forward_f32(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab, ACT_NONE);
   hipLaunchKernelGGL(vlm_argmax_kernel, dim3(B), dim3(256), 0, c.stream, lg, m.vocab, next_dev);
   FE_HIP(hipGetLastError());

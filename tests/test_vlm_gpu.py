@@ -81,6 +81,23 @@ def test_device_resident_generate_equals_the_stepwise_path(vlm_engine):
     assert np.array_equal(cut[0, :5], full[0, :5]) and (cut[0, 4:] == full[0, 4]).all()
 
 
+def test_decode_kernels_agree_across_batch_sizes(vlm_engine):
+    """The three decode projection paths - streaming GEMV (<= 4 sequences), weight-streaming matrix-core GEMM with a K split (5 .. 32),
+    the shared tiled GEMM (> 32) - on the same sequences: 4 prompts alone, the same 4 inside batches of 8, 32 and 40. Planted read-out,
+    so the token ids must be identical; logits within one bf16 unit of their scale (different summation orders of the same products)."""
+    e = vlm_engine
+    e.load_weights(FE_MODEL_VLM, _planted(7))
+    rng = np.random.default_rng(12)
+    p4 = rng.integers(0, 2048, (4, 21)).astype(np.int32)
+    t4, l4 = e.vlm_generate(p4, 6, want_logits=True)
+    for B in (8, 32, 40):
+        pb = np.concatenate([p4] + [rng.integers(0, 2048, (B - 4, 21)).astype(np.int32)], 0)
+        tb, lb = e.vlm_generate(pb, 6, want_logits=True)
+        assert np.array_equal(tb[:4], t4), B
+        assert np.abs(lb[:4] - l4).max() <= 0.125, (B, float(np.abs(lb[:4] - l4).max()))
+        assert np.array_equal(e.vlm_generate(pb, 6)[:4], t4), B          # device-resident loop, same kernels
+
+
 def test_teacher_forced_logits_of_the_random_checkpoint(vlm_engine):
     e = vlm_engine
     e.load_weights(FE_MODEL_VLM, synthetic_state_dict("qwen2_5_vl_text_tiny", int(G["seed_w"])))
