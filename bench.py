@@ -174,6 +174,63 @@ def cpu_baseline(sample, hw, seed_w, workload="topiq"):
                       f"threads on {cpu_model}; TOPIQ/SAMP one image per forward, CLIP one batch)"}
 
 
+def vlm_sub(dev_index, progress, layers=4):
+    """BASELINE configs[4] (24gb profile: Qwen2.5-VL-7B tagger, models/vlm_tagger.py): the engine's vision tower + text decoder at the 7B
+    geometry on seeded weights. The FULL 32-block vision tower; `layers` of the 28 decoder layers plus the whole 152064-row lm_head (the
+    per-layer work is what is measured; drawing 7.6 G synthetic parameters would take minutes - the 28-layer figures are extrapolated
+    from the per-layer time and say so). bf16, as the reference loads the model. Units: tokens/s and images/s, not the metric's."""
+    from facet_amd import Engine
+    from facet_amd._lib import FE_MODEL_VLM
+    from facet_amd.weights import synthetic_state_dict, qwen2_5_vl_text_spec, qwen2_5_vl_vision_spec
+    from facet_amd.vlm_tagger import vision_indices
+    H, NH, NKV, INTER, V = 3584, 28, 4, 18944, 152064
+    sd = synthetic_state_dict(None, 3, spec=qwen2_5_vl_text_spec(hidden=H, layers=layers, heads=NH, kv_heads=NKV, inter=INTER, vocab=V) + qwen2_5_vl_vision_spec())
+    e = Engine(dev_index, arena_bytes=40 << 30)
+    try:
+        e.vlm_configure(NH, NKV, 128, 1e6, 1e-6, (16, 24, 24))
+        e.vlm_vision_configure(16, (7, 15, 23, 31))
+        e.load_weights(FE_MODEL_VLM, sd)
+        del sd
+        progress("vlm context ready (Qwen2.5-VL-7B geometry)")
+        layer_p = H * (NH + 2 * NKV) * 128 + NH * 128 * H + 3 * H * INTER
+        full_scale = lambda ms_l, ms_head: ms_l * 28 / layers + ms_head
+        out = {"model": f"Qwen2.5-VL-7B geometry, seeded weights, bf16; vision tower 32 blocks; {layers} of 28 decoder layers + full lm_head measured",
+               "reference": "models/vlm_tagger.py:163-184, 245-259 (transformers Qwen2_5_VLForConditionalGeneration, generate(do_sample=False))"}
+        n_img = 8
+        idx = vision_indices([[1, 74, 74]] * n_img)
+        pv = np.random.default_rng(0).normal(0, 1, (74 * 74 * n_img, 1176)).astype(np.float32)
+        e.vlm_encode_images(pv, idx["patch_pos_hw"], idx["window_index"], idx["cu_window_seqlens"], idx["cu_seqlens"], want_embeds=False)
+        e.timer_start()
+        e.vlm_encode_images(pv, idx["patch_pos_hw"], idx["window_index"], idx["cu_window_seqlens"], idx["cu_seqlens"], want_embeds=False)
+        ms = e.timer_stop()
+        out["vision_tower"] = {"images_per_s": round(n_img / ms * 1e3, 1), "image": "1036x1036 px = 74x74 patches -> 1369 image tokens", "batch": n_img,
+                               "note": "host patches uploaded inside the call"}
+        steps = 16
+        for B in (2, 32):      # the reference's vlm_batch_size, and configs[4]'s batch
+            L = 512
+            p = np.random.default_rng(B).integers(0, V, (B, L)).astype(np.int32)
+            e.vlm_prefill(p, max_seq=L + steps + 8)
+            e.timer_start(); nxt = e.vlm_prefill(p, max_seq=L + steps + 8); t_pre = e.timer_stop()
+            pos = np.full((3, B), L, np.int32)
+            e.vlm_decode_step(nxt, pos)
+            t0 = time.perf_counter()
+            for s_ in range(steps):
+                nxt = e.vlm_decode_step(nxt, pos + 1 + s_)
+            t_dec = (time.perf_counter() - t0) / steps * 1e3
+            wbytes = 2.0 * (layers * layer_p + V * H)
+            w_full = 2.0 * (28 * layer_p + V * H)
+            t_full = t_dec * w_full / wbytes
+            out[f"batch_{B}"] = {"prefill_tokens_per_s": round(B * L / t_pre * 1e3), "prefill_tflops": round(2.0 * layers * layer_p * B * L / t_pre / 1e9, 1),
+                                 "decode_ms_per_step_measured": round(t_dec, 3), "decode_weight_GBps": round(wbytes / t_dec / 1e6),
+                                 "decode_frac_of_hbm_peak": round(wbytes / t_dec / 1e6 / 8000, 3),
+                                 "decode_ms_per_step_28_layers_extrapolated": round(t_full, 2),
+                                 "decode_tokens_per_s_28_layers_extrapolated": round(B / t_full * 1e3)}
+        progress(f"sub.vlm_tagger: vision {out['vision_tower']['images_per_s']} images/s, decode {out['batch_32']['decode_ms_per_step_measured']} ms/step at batch 32")
+        return out
+    finally:
+        e.close()
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` typed directly: start N fresh rank processes. Runs before this process imports torch or the
     engine, so no process that touched the GPU is ever replaced or re-executed; the children's stdout (rank 0's JSON line) passes
@@ -487,6 +544,8 @@ def main():
                     "roofline": roofline(wl, s_steps, evs, fl, fx, fh, e, pol)}
     if spare is not None:
         spare.close()
+    if rank == 0 and not (args.no_sub or world > 1) and args.dtype == "f32" and primary == "full":
+        sub["vlm_tagger"] = vlm_sub(dev_index, progress)      # BASELINE configs[4]'s model: its own metric (tokens/s), not images/s
     if rank == 0:
         if sub:
             out["sub"] = sub

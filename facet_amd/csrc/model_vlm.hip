@@ -350,17 +350,22 @@ __global__ __launch_bounds__(256) void vlm_gemv_kernel(const bf16* __restrict__ 
   float a0[MR], a1[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) { a0[m] = 0.f; a1[m] = 0.f; }
+  // products on v_dot2c_f32_bf16 (two bf16 pairs per instruction, fp32 accumulate): no unpacking of either operand - with it the
+  // 2- and 4-sequence steps were bound by the vector ALU, not by the weight stream
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  auto dot8 = [](const uint4 p, const uint4 q, float acc) __attribute__((always_inline)) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, p.x), __builtin_bit_cast(bf2, q.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, p.y), __builtin_bit_cast(bf2, q.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, p.z), __builtin_bit_cast(bf2, q.z), acc, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, p.w), __builtin_bit_cast(bf2, q.w), acc, false);
+  };
   auto fma8 = [&](const uint4 wa, const uint4 wb, const int k) __attribute__((always_inline)) {
-    float u[8], v[8];
-    h_unpack8_bf16(wa, u);
-    h_unpack8_bf16(wb, v);
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       if (m < M) {
-        float xs[8];
-        h_unpack8_bf16(*reinterpret_cast<const uint4*>(x + (size_t)m * ldx + k), xs);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { a0[m] += xs[e] * u[e]; a1[m] += xs[e] * v[e]; }
+        const uint4 xs = *reinterpret_cast<const uint4*>(x + (size_t)m * ldx + k);
+        a0[m] = dot8(xs, wa, a0[m]);
+        a1[m] = dot8(xs, wb, a1[m]);
       }
     }
   };
