@@ -112,7 +112,9 @@ ConvW pack_conv(DeviceWeights& dw, const HostTensor& w, const std::vector<float>
   }
   static const int wino_min_cin = getenv("FE_WINO_MIN_CIN") ? atoi(getenv("FE_WINO_MIN_CIN")) : 96;   // tuning hooks; defaults measured best (profiles/r01_README.md)
   static const int wino_form = getenv("FE_WINO_FORM") ? atoi(getenv("FE_WINO_FORM")) : 4;
-  if (!skip_f32 && (wino_form == 2 || wino_form == 4) && c.KH == 3 && c.KW == 3 && c.Cin == c.CinPad && c.Cin % 32 == 0 && c.Cin >= wino_min_cin && c.Cout % 4 == 0) {
+  // (Winograd forms serve the fp32 conv path only: a model committed under a 2-byte precision never runs them - its layers take the
+  // 2-byte kernel, or the direct fp32 kernel through the conversion fallback)
+  if (!skip_f32 && dw.prec == PREC_F32 && (wino_form == 2 || wino_form == 4) && c.KH == 3 && c.KW == 3 && c.Cin == c.CinPad && c.Cin % 32 == 0 && c.Cin >= wino_min_cin && c.Cout % 4 == 0) {
     // Winograd weights U = G g G^T per (cout, cin), in double. Layout [planes][Cout][Cin]; the epilogue scale / shift / activation
     // are applied by the output transform (ConvW.scale may be attached after packing).
     static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};

@@ -107,28 +107,6 @@ __global__ void vlm_last_rows_kernel(const bf16* __restrict__ x, bf16* __restric
   const int b = i / d, c = i - b * d;
   last[i] = x[((size_t)b * L + L - 1) * d + c];
 }
-// logits rounded to bf16 (what lm_head emits on a bf16 model), widened back into `lg`; next[b] = first index of the row maximum
-// (torch.argmax's tie rule on equal bf16 values). One block per row.
-__global__ void vlm_argmax_kernel(float* __restrict__ lg, int vocab, int* __restrict__ next) {
-  float* row = lg + (size_t)blockIdx.x * vocab;
-  float best = -INFINITY; int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < vocab; i += blockDim.x) {
-    const float v = (float)(bf16)row[i];
-    row[i] = v;
-    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
-  }
-  __shared__ float sv[256]; __shared__ int si[256];
-  sv[threadIdx.x] = best; si[threadIdx.x] = bi;
-  __syncthreads();
-  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      const float v = sv[threadIdx.x + o]; const int j = si[threadIdx.x + o];
-      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && j < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = j; }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) next[blockIdx.x] = si[0];
-}
 
 // ---- prefill attention: causal, grouped-query, head_dim 128, on the bf16 matrix cores --------------------------------------------------
 // One wave owns 32 queries; a workgroup (4 waves = 128 queries) shares 32-key K / V tiles through LDS. Same scheme as
@@ -261,66 +239,6 @@ __global__ __launch_bounds__(256, 2) void vlm_attn_prefill_kernel(const VlmAttnP
       for (int g = 0; g < 4; ++g)
         st4(op + dt * 32 + 8 * g + 4 * h, make_float4(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv));
   }
-}
-
-// ---- decode attention: one query per (sequence, head) over the whole cache - a pure streaming pass over K then V (HBM-bound: the
-// keys and values of a head are read once per step). One workgroup per (b, head): scores -> LDS, softmax, weighted sum of V rows.
-__global__ __launch_bounds__(256) void vlm_attn_decode_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kc, const bf16* __restrict__ vc, bf16* __restrict__ o,
-                                                              int nh, int nkv, int Lk, int max_seq, float scale, const int* __restrict__ len_dev) {
-  if (len_dev) Lk = *len_dev + 1;       // (graph replay: keys 0 .. cache length, the new token included)
-  extern __shared__ float sc[];        // [Lk] scores / probabilities, then 4 x 128 partial outputs
-  __shared__ float qs[128];
-  __shared__ float red[8];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int b = blockIdx.x / nh, head = blockIdx.x - b * nh, kvh = head / (nh / nkv);
-  const bf16* K = kc + ((size_t)b * nkv + kvh) * max_seq * 128;
-  const bf16* V = vc + ((size_t)b * nkv + kvh) * max_seq * 128;
-  if (t < 128) qs[t] = (float)q[((size_t)b * nh + head) * 128 + t];
-  __syncthreads();
-  float mx = -INFINITY;
-  for (int key = t; key < Lk; key += 256) {
-    const bf16* kr = K + (size_t)key * 128;
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      float v[8];
-      const uint4 u = *reinterpret_cast<const uint4*>(kr + 8 * c);
-      fe_unpack2((const bf16*)nullptr, u.x, v[0], v[1]); fe_unpack2((const bf16*)nullptr, u.y, v[2], v[3]);
-      fe_unpack2((const bf16*)nullptr, u.z, v[4], v[5]); fe_unpack2((const bf16*)nullptr, u.w, v[6], v[7]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += v[e] * qs[8 * c + e];
-    }
-    acc *= scale;
-    sc[key] = acc;
-    mx = fmaxf(mx, acc);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float sum = 0.f;
-  for (int key = t; key < Lk; key += 256) { const float e = __expf(sc[key] - mx); sc[key] = e; sum += e; }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-  if (lane == 0) red[4 + wave] = sum;
-  __syncthreads();
-  const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-  // O: lane owns dims 2 lane, 2 lane + 1; wave w takes keys w, w + 4, ...; probabilities rounded to bf16 like the P operand of the
-  // matrix-core path
-  float a0 = 0.f, a1 = 0.f;
-  for (int key = wave; key < Lk; key += 4) {
-    const float pj = (float)(bf16)(sc[key] * inv);
-    const unsigned u = *reinterpret_cast<const unsigned*>(V + (size_t)key * 128 + 2 * lane);
-    float v0, v1;
-    fe_unpack2((const bf16*)nullptr, u, v0, v1);
-    a0 += pj * v0; a1 += pj * v1;
-  }
-  __syncthreads();      // everyone is done with sc[] as probabilities
-  float* part = sc;     // reuse: [4][128]
-  part[wave * 128 + 2 * lane] = a0; part[wave * 128 + 2 * lane + 1] = a1;
-  __syncthreads();
-  if (t < 128) o[((size_t)b * nh + head) * 128 + t] = (bf16)(part[t] + part[128 + t] + part[256 + t] + part[384 + t]);
 }
 
 // x[index[i]][:] = rows[i][:]   (image embeddings into the rows of their <|image_pad|> tokens)
@@ -515,6 +433,149 @@ __global__ void vlm_advance_kernel(const int* __restrict__ next, int* __restrict
   if (b == 0) { *len += 1; *step = st + 1; }
 }
 
+// x = bf16(x + y) and, in the same pass, n = RMSNorm(x) * w (w == nullptr: the sum only). One wave per row: a decode step is a chain of
+// ~12 launches per layer whose small ones cost their launch latency, so the residual sum rides with the norm that follows it.
+__global__ void vlm_add_rmsnorm_kernel(bf16* __restrict__ x, const bf16* __restrict__ y, const bf16* __restrict__ w, bf16* __restrict__ n, int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int row = wave; row < rows; row += nwaves) {
+    bf16* xr = x + (size_t)row * d;
+    const bf16* yr = y + (size_t)row * d;
+    float ss = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+      const float4 a = ld4(xr + i), b = ld4(yr + i);
+      // the sum is rounded to bf16 first (the residual stream is a bf16 tensor), and the norm reads the rounded value
+      const float4 v = make_float4((float)(bf16)(a.x + b.x), (float)(bf16)(a.y + b.y), (float)(bf16)(a.z + b.z), (float)(bf16)(a.w + b.w));
+      st4(xr + i, v);
+      ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (!w) continue;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rs = rsqrtf(ss / (float)d + eps);
+    bf16* nr = n + (size_t)row * d;
+    for (int i = lane * 4; i < d; i += 256) {
+      const float4 v = ld4(xr + i), g = ld4(w + i);      // (this lane's own stores of the first loop)
+      st4(nr + i, make_float4(g.x * (float)(bf16)(v.x * rs), g.y * (float)(bf16)(v.y * rs), g.z * (float)(bf16)(v.z * rs), g.w * (float)(bf16)(v.w * rs)));
+    }
+  }
+}
+
+// argmax over a vocabulary row in two launches (one 256-thread block walked 152064 logits in 180 us): 64 chunks per row, then one wave
+// per row over the 64 partial results. Logits are rounded to bf16 in place first; ties go to the lowest index (torch.argmax).
+constexpr int VLM_AM_CHUNKS = 64;
+__global__ void vlm_argmax_part_kernel(float* __restrict__ lg, int vocab, float* __restrict__ pv, int* __restrict__ pi) {
+  float* row = lg + (size_t)blockIdx.y * vocab;
+  const int per = (vocab + VLM_AM_CHUNKS - 1) / VLM_AM_CHUNKS, i0 = blockIdx.x * per, i1 = min(i0 + per, vocab);
+  float best = -INFINITY; int bi = 0x7fffffff;
+  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const float v = (float)(bf16)row[i];
+    row[i] = v;
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+  __shared__ float sv[256]; __shared__ int si[256];
+  sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const float v = sv[threadIdx.x + o]; const int j = si[threadIdx.x + o];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && j < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = j; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { pv[blockIdx.y * VLM_AM_CHUNKS + blockIdx.x] = sv[0]; pi[blockIdx.y * VLM_AM_CHUNKS + blockIdx.x] = si[0]; }
+}
+__global__ void vlm_argmax_final_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int* __restrict__ next) {
+  const int b = blockIdx.x, t = threadIdx.x;      // 64 threads = one wave
+  float v = pv[b * VLM_AM_CHUNKS + t]; int j = pi[b * VLM_AM_CHUNKS + t];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_xor(v, o); const int j2 = __shfl_xor(j, o);
+    if (v2 > v || (v2 == v && j2 < j)) { v = v2; j = j2; }
+  }
+  if (t == 0) next[b] = j;
+}
+
+// Decode attention with the keys split over workgroups (one (sequence, head) alone kept 28 of 256 CUs busy for 43 us per layer): block
+// (bh, s) takes keys [256 s, 256 s + 256), writes its unnormalised output, running maximum and sum; vlm_attn_combine_kernel merges the
+// chunks of a head. Lk by value or, for graph replay, from device memory (then the grid covers the whole cache and chunks past Lk exit).
+constexpr int VLM_DEC_CHUNK = 256;
+__global__ __launch_bounds__(256) void vlm_attn_decode_split_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kc, const bf16* __restrict__ vc, float* __restrict__ po,
+                                                                    float* __restrict__ pm, float* __restrict__ pl, int nh, int nkv, int Lk, int max_seq, float scale,
+                                                                    const int* __restrict__ len_dev, int nsplit) {
+  __shared__ float sc[VLM_DEC_CHUNK];
+  __shared__ float qs[128];
+  __shared__ float red[8];
+  __shared__ float part[4 * 128];
+  if (len_dev) Lk = *len_dev + 1;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int bh = blockIdx.x, sp = blockIdx.y;
+  const int b = bh / nh, head = bh - b * nh, kvh = head / (nh / nkv);
+  const int k0 = sp * VLM_DEC_CHUNK, k1 = min(k0 + VLM_DEC_CHUNK, Lk);
+  if (k0 >= Lk) {      // a chunk past the cache length: neutral element of the merge
+    if (t == 0) { pm[(size_t)bh * nsplit + sp] = -INFINITY; pl[(size_t)bh * nsplit + sp] = 0.f; }
+    return;
+  }
+  const bf16* K = kc + ((size_t)b * nkv + kvh) * max_seq * 128;
+  const bf16* V = vc + ((size_t)b * nkv + kvh) * max_seq * 128;
+  if (t < 128) qs[t] = (float)q[((size_t)b * nh + head) * 128 + t];
+  __syncthreads();
+  float s = -INFINITY;
+  const int key = k0 + t;
+  if (key < k1) {
+    const bf16* kr = K + (size_t)key * 128;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float v[8];
+      h_unpack8_bf16(*reinterpret_cast<const uint4*>(kr + 8 * c), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += v[e] * qs[8 * c + e];
+    }
+    s = acc * scale;
+  }
+  float mx = s;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float e = key < k1 ? __expf(s - mx) : 0.f;
+  sc[t] = e;
+  float sum = e;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  // partial O: lane owns dims 2 lane, 2 lane + 1; wave w takes keys w, w + 4, ... of the chunk; probabilities as bf16 (the P operand)
+  float a0 = 0.f, a1 = 0.f;
+  for (int j = wave; j < k1 - k0; j += 4) {
+    const float pj = (float)(bf16)sc[j];
+    const unsigned u = *reinterpret_cast<const unsigned*>(V + (size_t)(k0 + j) * 128 + 2 * lane);
+    float v0, v1;
+    fe_unpack2((const bf16*)nullptr, u, v0, v1);
+    a0 += pj * v0; a1 += pj * v1;
+  }
+  part[wave * 128 + 2 * lane] = a0; part[wave * 128 + 2 * lane + 1] = a1;
+  __syncthreads();
+  if (t < 128) po[((size_t)bh * nsplit + sp) * 128 + t] = (part[t] + part[128 + t]) + (part[256 + t] + part[384 + t]);
+  if (t == 0) { pm[(size_t)bh * nsplit + sp] = mx; pl[(size_t)bh * nsplit + sp] = (red[4] + red[5]) + (red[6] + red[7]); }
+}
+__global__ void vlm_attn_combine_kernel(const float* __restrict__ po, const float* __restrict__ pm, const float* __restrict__ pl, bf16* __restrict__ o, int nsplit) {
+  const int bh = blockIdx.x, t = threadIdx.x;      // 128 threads: one per output dimension
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pm[(size_t)bh * nsplit + s]);
+  float l = 0.f, acc = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float mm = pm[(size_t)bh * nsplit + s];
+    if (mm == -INFINITY) continue;
+    const float f = __expf(mm - M);
+    l += f * pl[(size_t)bh * nsplit + s];
+    acc += f * po[((size_t)bh * nsplit + s) * 128 + t];
+  }
+  o[(size_t)bh * 128 + t] = (bf16)(acc / l);
+}
+
 // ---- model ---------------------------------------------------------------------------------------------------------------------------
 static bf16* upload_bf16(DeviceWeights& dw, const std::vector<float>& v) {
   std::vector<uint16_t> h(v.size());
@@ -628,15 +689,21 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
   bf16* gg = c.arena.array<bf16>((size_t)rows * m.inter);
   bf16* uu = c.arena.array<bf16>((size_t)rows * m.inter);
   const float scale = 1.0f / sqrtf(128.f);
+  // decode attention: keys split over workgroups, merged by a second launch (graph replay: the grid covers the whole cache)
+  const int nsplit = L == 1 ? ((len_dev ? m.max_seq : Lk) + VLM_DEC_CHUNK - 1) / VLM_DEC_CHUNK : 0;
+  float* po = nsplit ? c.arena.array<float>((size_t)B * nh * nsplit * 128) : nullptr;
+  float* pm = nsplit ? c.arena.array<float>((size_t)B * nh * nsplit) : nullptr;
+  float* pl = nsplit ? c.arena.array<float>((size_t)B * nh * nsplit) : nullptr;
+  hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, (const bf16*)x, d, (const bf16*)m.layers[0].ln1, n, d, rows, d, g.rms_eps);
   for (size_t li = 0; li < m.layers.size(); ++li) {
     const VlmLayerW& w = m.layers[li];
-    hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, (const bf16*)x, d, (const bf16*)w.ln1, n, d, rows, d, g.rms_eps);
     vlm_linear(c, w.qkv, (const bf16*)n, d, rows, qkv, qkvd);
     hipLaunchKernelGGL(vlm_rope_cache_kernel, dim3(grid_n((size_t)rows * (nh + 2 * nkv) * 64)), dim3(256), 0, c.stream, (const bf16*)qkv, pos, (const float*)m.inv_freq, qr,
                        m.kcache[li], m.vcache[li], rows, L, nh, nkv, g.mrope[0], g.mrope[1], start, m.max_seq, L == 1 ? len_dev : (const int*)nullptr);
     if (L == 1) {
-      hipLaunchKernelGGL(vlm_attn_decode_kernel, dim3(B * nh), dim3(256), (size_t)std::max(len_dev ? m.max_seq : Lk, 512) * sizeof(float), c.stream, (const bf16*)qr,
-                         (const bf16*)m.kcache[li], (const bf16*)m.vcache[li], ao, nh, nkv, Lk, m.max_seq, scale, len_dev);
+      hipLaunchKernelGGL(vlm_attn_decode_split_kernel, dim3(B * nh, nsplit), dim3(256), 0, c.stream, (const bf16*)qr, (const bf16*)m.kcache[li], (const bf16*)m.vcache[li],
+                         po, pm, pl, nh, nkv, Lk, m.max_seq, scale, len_dev, nsplit);
+      hipLaunchKernelGGL(vlm_attn_combine_kernel, dim3(B * nh), dim3(128), 0, c.stream, (const float*)po, (const float*)pm, (const float*)pl, ao, nsplit);
     } else {
       VlmAttnParams ap{qr, qd, m.kcache[li], m.vcache[li], ao, qd, B, nh, nkv, L, Lk, m.max_seq, start, scale};
       hipLaunchKernelGGL(vlm_attn_prefill_kernel, dim3((L + 127) / 128, B * nh), dim3(256), 0, c.stream, ap);
@@ -645,13 +712,14 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
     c.flops_accum += 4.0 * B * nh * (double)L * (start + (L + 1) * 0.5) * 128;
     c.flops_half += 4.0 * B * nh * (double)L * (start + (L + 1) * 0.5) * 128;
     vlm_linear(c, w.o, (const bf16*)ao, qd, rows, br, d);
-    hipLaunchKernelGGL(vlm_add_kernel, dim3(grid_n((size_t)rows * d / 4)), dim3(256), 0, c.stream, x, (const bf16*)br, (size_t)rows * d / 4);
-    hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, (const bf16*)x, d, (const bf16*)w.ln2, n, d, rows, d, g.rms_eps);
+    hipLaunchKernelGGL(vlm_add_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, x, (const bf16*)br, (const bf16*)w.ln2, n, rows, d, g.rms_eps);
     vlm_linear(c, w.gate, (const bf16*)n, d, rows, gg, m.inter);
     vlm_linear(c, w.up, (const bf16*)n, d, rows, uu, m.inter);
     hipLaunchKernelGGL(vlm_silu_mul_kernel, dim3(grid_n((size_t)rows * m.inter / 4)), dim3(256), 0, c.stream, (const bf16*)gg, (const bf16*)uu, gg, (size_t)rows * m.inter / 4);
     vlm_linear(c, w.down, (const bf16*)gg, m.inter, rows, br, d);
-    hipLaunchKernelGGL(vlm_add_kernel, dim3(grid_n((size_t)rows * d / 4)), dim3(256), 0, c.stream, x, (const bf16*)br, (size_t)rows * d / 4);
+    // x += down(...) and, in the same launch, the next layer's input norm (none after the last layer)
+    hipLaunchKernelGGL(vlm_add_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, x, (const bf16*)br,
+                       li + 1 < m.layers.size() ? (const bf16*)m.layers[li + 1].ln1 : (const bf16*)nullptr, n, rows, d, g.rms_eps);
     FE_HIP(hipGetLastError());
   }
   // final norm + lm_head on the last position of every sequence
@@ -663,7 +731,10 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
   if (B <= 4) vlm_gemv(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab);
   else if (B <= 32 && d % 64 == 0) vlm_gemm32(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab);
   else linear_forward_f32(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab, ACT_NONE);
-  hipLaunchKernelGGL(vlm_argmax_kernel, dim3(B), dim3(256), 0, c.stream, lg, m.vocab, next_dev);
+  float* apv = c.arena.array<float>((size_t)B * VLM_AM_CHUNKS);
+  int* api = c.arena.array<int>((size_t)B * VLM_AM_CHUNKS);
+  hipLaunchKernelGGL(vlm_argmax_part_kernel, dim3(VLM_AM_CHUNKS, B), dim3(256), 0, c.stream, lg, m.vocab, apv, api);
+  hipLaunchKernelGGL(vlm_argmax_final_kernel, dim3(B), dim3(64), 0, c.stream, (const float*)apv, (const int*)api, next_dev);
   FE_HIP(hipGetLastError());
   m.cur_len = Lk;
   c.arena.rewind(mark);
