@@ -74,6 +74,8 @@ SIGNATURES = {
     "fe_model_loaded": (C.c_int, [C.c_void_p, C.c_int]),
     "fe_op_conv2d": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int,
                                C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
+    "fe_op_topiq_gate64": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float,
+                                     _f32p, _f32p, C.c_int, C.c_int, _f32p]),
     "fe_op_maxpool2d": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, _f32p]),
     "fe_op_bilinear": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
@@ -342,6 +344,17 @@ class Engine:
             res, rp = _f32(res)
         self._ck(self.lib.fe_op_conv2d(self.h, xp, n, c, h, ww, wp, cout, kh, kw, sp, hp, rp, int(res_after_act),
                                        stride, pad, dil, ACT[act], y.ctypes.data_as(_f32p)))
+        return y
+
+    def topiq_gate64(self, x, w0, b0, w2, b2, w4, b4, wx, bx, wblk_act="gelu", gate_act="gelu"):
+        """Test hook of the fused gate + 16x16 pool of TOPIQ's 64-channel level (2-byte precisions): x [n, 64, h, w]."""
+        x, xp = _f32(x)
+        n, c, h, w = x.shape
+        assert c == 64
+        arrs = [_f32(a) for a in (w0, b0, w2, b2, w4, wx, bx)]
+        y = np.empty((n, 64, h // 16, w // 16), np.float32)
+        self._ck(self.lib.fe_op_topiq_gate64(self.h, xp, n, h, w, arrs[0][1], arrs[1][1], arrs[2][1], arrs[3][1], arrs[4][1], C.c_float(float(b4)),
+                                             arrs[5][1], arrs[6][1], ACT[wblk_act], ACT[gate_act], y.ctypes.data_as(_f32p)))
         return y
 
     def maxpool2d(self, x, k, stride, pad=0, ceil_mode=False):

@@ -596,6 +596,28 @@ int fe_op_conv2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, const 
   FE_API_END(ctx)
 }
 
+int fe_op_topiq_gate64(fe_ctx* ctx, const float* x, int n, int h, int w, const float* w0, const float* b0, const float* w2, const float* b2,
+                       const float* w4, float b4, const float* wx, const float* bx, int wblk_act, int gate_act, float* y) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(x && w0 && b0 && w2 && b2 && w4 && wx && bx && y && n > 0 && h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0, "bad gate64 arguments");
+  FE_CHECK(C.precision == PREC_BF16 || C.precision == PREC_F16, "fe_op_topiq_gate64: the fused gate exists for the 2-byte element types only");
+  C.arena.reset();
+  DeviceWeights dw;
+  dw.prec = C.precision;
+  GatedConvW g;
+  build_gate64_fragments(dw, g, w0, b0, w2, b2, w4, b4, wx, bx);
+  auto run = [&](auto* tag) {
+    typedef std::remove_pointer_t<decltype(tag)> E;
+    TensorT<E> xt = upload_nchw<E>(C, x, n, 64, h, w, 64);
+    TensorT<E> yt = C.arena.tensor_t<E>(n, h / 16, w / 16, 64);
+    launch_topiq_gate64(xt, yt, g.fused, g.fused_bias, wblk_act, gate_act, C.stream);
+    download_nchw(C, yt, 64, y);
+  };
+  if (C.precision == PREC_BF16) run((bf16*)nullptr); else run((f16*)nullptr);
+  FE_API_END(ctx)
+}
+
 int fe_op_maxpool2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int k, int stride, int pad, int ceil_mode,
                     float* y) {
   FE_API_BEGIN(ctx)

@@ -125,7 +125,7 @@ __device__ __forceinline__ void h_epilogue_wide(h_f32x16 (&acc)[TM][TN], const C
           if (RES && !p.res_after_act) x += rf;
           if (ACTK == 1) x = x > 0.f ? x : 0.f;
           else if (ACTK == 2) x = fe_gelu_fast(x);
-          else if (ACTK == 3) x = __frcp_rn(1.f + __expf(-x));
+          else if (ACTK == 3) x = fe_rcp_fast(1.f + __expf(-x));
           else if (ACTK < 0) x = fe_apply_act_fast(x, p.act);
           if (RES && p.res_after_act) x += rf;
           if (GATE) x *= gf4[e];

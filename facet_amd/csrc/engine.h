@@ -235,7 +235,16 @@ struct Ctx {
 // pre-norm transformer layers of pyiqa's CFANet (DETR-style) [DEP-KNOWLEDGE]
 struct EncLayerW { MHAW attn; ConvW lin1, lin2; LayerNormW n1, n2; };
 struct DecLayerW { MHAW cross; ConvW lin1, lin2; LayerNormW n1, n2, n3; };
-struct GatedConvW { ConvW split_x1, w0, w2, w4; };  // w0 = weight_blk[0] composed with the x2 half of splitconv
+struct GatedConvW {
+  ConvW split_x1, w0, w2, w4;   // w0 = weight_blk[0] composed with the x2 half of splitconv
+  // 64-channel level of a 2-byte model: the whole gate + its 16 x 16 average pool as ONE launch (kernels_gate.hip); null otherwise
+  void* fused = nullptr;
+  float* fused_bias = nullptr;
+};
+void build_gate64_fragments(DeviceWeights& dw, GatedConvW& g, const float* W0, const float* B0, const float* W2, const float* B2, const float* W4, float b4,
+                            const float* Wx, const float* Bx);
+template <class E>
+void launch_topiq_gate64(const TensorT<E>& x, const TensorT<E>& out, const void* frag, const float* bias, int wblk_act, int gate_act, hipStream_t s);
 
 struct TopiqModel {
   DeviceWeights dw;

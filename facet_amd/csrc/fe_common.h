@@ -51,12 +51,14 @@ __device__ __forceinline__ float fe_apply_act(float v, int act) {
   return v;
 }
 
+__device__ __forceinline__ float fe_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp (see fe_gelu_fast)
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute): ~12 instructions against ocml's erff (~40 with its branches). The GELU
 // built on it is within 1e-7 * |x| of the erf form - used where a result is NOT rounded to 2 bytes afterwards but fp32's last bits do
 // not matter either (the split-pair and fp32-stream epilogues of the 2-byte kernels; the fp32 kernels keep erff).
 __device__ __forceinline__ float fe_erf_as(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = fe_rcp_fast(1.0f + 0.3275911f * ax);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float r = 1.0f - poly * __expf(-ax * ax);
   return copysignf(r, x);
@@ -72,15 +74,18 @@ __device__ __forceinline__ float fe_apply_act_precise(float v, int act) {      /
 // GELU for epilogues whose result is rounded to bf16: the tanh form 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3), written as
 // x * sigmoid(2u) = x / (1 + 2^(-2u log2 e)): 3 multiply-adds, one v_exp, one add, one v_rcp, one multiply. It deviates from the erf
 // form by at most 4.8e-4 (at |x| ~ 2.7, where a bf16 ulp is 1.6e-2) and by < 2e-5 for |x| < 0.5 - below the rounding of the store.
+// The exponential and the reciprocal are the bare v_exp_f32 / v_rcp_f32 (1 ulp each): exp2f() wraps the instruction in a denormal
+// rescue (compare, two selects, add, ldexp) and __frcp_rn() expands to the IEEE division sequence (div_scale, rcp, four FMAs, div_fmas,
+// div_fixup) - ~30 instructions per value where 8 do; a flushed denormal 2^z only turns 1 + 2^z into 1, and z = +inf gives x * 0.
 __device__ __forceinline__ float fe_gelu_fast(float x) {
   const float x2 = x * x;
   const float z = x * (-2.3022082f - 0.10294324f * x2);       // -2 u log2(e)
-  return x * __frcp_rn(1.0f + exp2f(z));
+  return x * fe_rcp_fast(1.0f + __builtin_amdgcn_exp2f(z));
 }
 __device__ __forceinline__ float fe_apply_act_fast(float v, int act) {   // bf16 epilogues only
   if (act == ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == ACT_GELU) return fe_gelu_fast(v);
-  if (act == ACT_SIGMOID) return __frcp_rn(1.f + __expf(-v));
+  if (act == ACT_SIGMOID) return fe_rcp_fast(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
   if (act == ACT_SOFTPLUS) return fmaxf(v, 0.f) + __logf(1.f + __expf(-fabsf(v)));   // |error| ~1e-7: far below the bf16 rounding of the result
   return v;
 }

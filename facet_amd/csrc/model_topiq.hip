@@ -67,6 +67,12 @@ void build_topiq_head(TopiqModel& m, const WeightStore& ws) {
         Be.data[o] = (float)bacc;
       }
       m.gate[i].w0 = build_linear_rows(m.dw, We, &Be, 0, mid);
+      // the 64-channel level of a 2-byte model also gets the one-launch form of the whole gate + pool (kernels_gate.hip)
+      const HostTensor& W2g = ws.get(g + ".weight_blk.2.weight");
+      const HostTensor& W4g = ws.get(g + ".weight_blk.4.weight");
+      if (m.dw.prec != PREC_F32 && dim == 64 && mid == 64 && W2g.shape == std::vector<int64_t>{64, 64, 3, 3} && W4g.shape == std::vector<int64_t>{1, 64, 3, 3})
+        build_gate64_fragments(m.dw, m.gate[i], We.data.data(), Be.data.data(), W2g.data.data(), ws.get(g + ".weight_blk.2.bias").data.data(), W4g.data.data(),
+                               ws.get(g + ".weight_blk.4.bias").data[0], W.data.data(), B.data.data());
     }
     m.gate[i].w2 = build_conv(m.dw, ws, g + ".weight_blk.2", "", true);
     m.gate[i].w4 = build_conv(m.dw, ws, g + ".weight_blk.4", "", true);
@@ -190,6 +196,35 @@ void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<TensorT<T>>& fe
     const size_t mark = c.arena.mark();
     const TensorT<T>& f = feats[i];
     const GatedConvW& g = m.gate[i];
+    if constexpr (sizeof(T) == 2) {
+      const bool no_fused = getenv("FE_NO_FUSED_GATE") != nullptr;      // A/B hook, read per call (tests switch it inside one process)
+      if (g.fused && !no_fused && f.c == 64 && f.h == 16 * th && f.w == 16 * tw && f.ld % 8 == 0) {
+        // the 64-channel level: gate + 16 x 16 pool in one launch; FLOPs counted as the four convolutions it stands for
+        TensorT<T> pooled = c.arena.tensor_t<T>(B, th, tw, 64);
+        const double px = (double)f.pixels(), flops = 2.0 * px * (64.0 * 64 + 576.0 * 64 + 576.0 + 64.0 * 64);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c.profile) { FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1)); FE_HIP(hipEventRecord(e0, c.stream)); }
+        launch_topiq_gate64(f, pooled, g.fused, g.fused_bias, m.wblk_act, m.gate_act, c.stream);
+        if (c.profile) {
+          FE_HIP(hipEventRecord(e1, c.stream)); FE_HIP(hipEventSynchronize(e1));
+          float ms = 0.f;
+          FE_HIP(hipEventElapsedTime(&ms, e0, e1));
+          (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+          char nm[128];
+          snprintf(nm, sizeof nm, "%s fused gate64 + pool16 M=%d", PrecOf<T>::value == PREC_F16 ? "f16" : "bf16", (int)f.pixels());
+          c.timings.push_back({nm, flops, 2.0 * px * 64, ms});
+        }
+        c.flops_accum += flops; c.flops_half += flops;
+        TensorT<T> t = mat_view(tok[i], B * L, d, d);
+        t.n = B; t.h = th; t.w = tw;
+        ConvOptsT<T> od; od.act = ACT_GELU;
+        conv_forward(c, m.dim_reduce[i], pooled, t, od);
+        launch_add_rows_bcast(tok[i], d, pos, B * L, L, d, c.stream);
+        enc_forward(c, m.sa[i], tok[i], tok[i], B, L);
+        c.arena.rewind(mark);
+        continue;
+      }
+    }
     ConvOptsT<T> o0; o0.act = m.wblk_act;
     TensorT<T> wa = conv_new(c, g.w0, f, o0);    // = act(weight_blk[0](x2)) with x2 folded in (see build_topiq_head)
     ConvOptsT<T> o2; o2.act = m.wblk_act; o2.ph = o2.pw = 1;

@@ -157,6 +157,12 @@ int fe_model_loaded(fe_ctx* ctx, int model);   /* 1 / 0 */
 int fe_op_conv2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, const float* weight, int cout, int kh,
                  int kw, const float* scale, const float* shift, const float* res, int res_after_act, int stride,
                  int pad, int dil, int act, float* y);
+/* test hook of the fused TOPIQ gate of the 64-channel pyramid level (kernels_gate.hip; 2-byte precisions only): x [n][64][h][w] (h, w
+   multiples of 16), w0 / wx [64][64], w2 [64][64][3][3], w4 [1][64][3][3] ->
+   y [n][64][h/16][w/16] = mean_16x16( act_g(wx x + bx) * sigmoid(w4 * act_w(w2 * act_w(w0 x + b0) + b2) + b4) ) */
+int fe_op_topiq_gate64(fe_ctx* ctx, const float* x, int n, int h, int w, const float* w0, const float* b0, const float* w2,
+                       const float* b2, const float* w4, float b4, const float* wx, const float* bx, int wblk_act,
+                       int gate_act, float* y);
 int fe_op_maxpool2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int k, int stride, int pad,
                     int ceil_mode, float* y);
 int fe_op_bilinear(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int ho, int wo, float* y);
