@@ -76,6 +76,8 @@ SIGNATURES = {
                                C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "fe_op_topiq_gate64": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float,
                                      _f32p, _f32p, C.c_int, C.c_int, _f32p]),
+    "fe_op_conv3x3_c64": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p,
+                                    _f32p, _f32p]),
     "fe_op_maxpool2d": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, _f32p]),
     "fe_op_bilinear": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
@@ -355,6 +357,17 @@ class Engine:
         y = np.empty((n, 64, h // 16, w // 16), np.float32)
         self._ck(self.lib.fe_op_topiq_gate64(self.h, xp, n, h, w, arrs[0][1], arrs[1][1], arrs[2][1], arrs[3][1], arrs[4][1], C.c_float(float(b4)),
                                              arrs[5][1], arrs[6][1], ACT[wblk_act], ACT[gate_act], y.ctypes.data_as(_f32p)))
+        return y
+
+    def conv3x3_c64(self, x, w2, scale2=None, shift2=None, act2="relu", w3=None, scale3=None, shift3=None, res=None):
+        """Test hook of the halo-tiled 3x3 (64 -> 64) kernel and its chained 1x1 expand + identity + ReLU (2-byte precisions)."""
+        x, xp = _f32(x)
+        n, c, h, w = x.shape
+        assert c == 64
+        keep = [_f32(a) if a is not None else (None, None) for a in (w2, scale2, shift2, w3, scale3, shift3, res)]
+        y = np.empty((n, 256 if w3 is not None else 64, h, w), np.float32)
+        self._ck(self.lib.fe_op_conv3x3_c64(self.h, xp, n, h, w, keep[0][1], keep[1][1], keep[2][1], ACT[act2], keep[3][1], keep[4][1], keep[5][1],
+                                            keep[6][1], y.ctypes.data_as(_f32p)))
         return y
 
     def maxpool2d(self, x, k, stride, pad=0, ceil_mode=False):

@@ -618,6 +618,34 @@ int fe_op_topiq_gate64(fe_ctx* ctx, const float* x, int n, int h, int w, const f
   FE_API_END(ctx)
 }
 
+int fe_op_conv3x3_c64(fe_ctx* ctx, const float* x, int n, int h, int w, const float* w2, const float* scale2, const float* shift2, int act2,
+                      const float* w3, const float* scale3, const float* shift3, const float* res, float* y) {
+  FE_API_BEGIN(ctx)
+  Ctx& C = ctx->c;
+  FE_CHECK(x && w2 && y && n > 0 && h > 0 && w > 0 && (!w3 || res), "bad conv3x3_c64 arguments");
+  FE_CHECK(C.precision == PREC_BF16 || C.precision == PREC_F16, "fe_op_conv3x3_c64: the halo-tiled kernel exists for the 2-byte element types only");
+  C.arena.reset();
+  DeviceWeights dw;
+  dw.prec = C.precision;
+  void *f2 = nullptr, *f3 = nullptr;
+  build_c64_fragments(dw, w2, w3, &f2, &f3);
+  std::vector<float> v;
+  auto up = [&](const float* a, int cnt) -> float* { if (!a) return nullptr; v.assign(a, a + cnt); return dw.upload(v); };
+  float *s2 = up(scale2, 64), *h2 = up(shift2, 64), *s3 = up(scale3, 256), *h3 = up(shift3, 256);
+  const int cout = w3 ? 256 : 64;
+  auto run = [&](auto* tag) {
+    typedef std::remove_pointer_t<decltype(tag)> E;
+    TensorT<E> xt = upload_nchw<E>(C, x, n, 64, h, w, 64);
+    TensorT<E> yt = C.arena.tensor_t<E>(n, h, w, cout);
+    TensorT<E> rt;
+    if (w3) rt = upload_nchw<E>(C, res, n, 256, h, w, 256);
+    launch_conv3x3_c64(xt, yt, w3 ? &rt : nullptr, f2, f3, s2, h2, s3, h3, act2, C.stream);
+    download_nchw(C, yt, cout, y);
+  };
+  if (C.precision == PREC_BF16) run((bf16*)nullptr); else run((f16*)nullptr);
+  FE_API_END(ctx)
+}
+
 int fe_op_maxpool2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int k, int stride, int pad, int ceil_mode,
                     float* y) {
   FE_API_BEGIN(ctx)

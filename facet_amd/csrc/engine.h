@@ -162,7 +162,15 @@ struct ResBlock {
   ConvW c1, c2, c3, down;
   bool has_down = false, bottleneck = true;
   int stride = 1;
+  // stride-1 bottlenecks with a 64-channel 3x3 of a 2-byte model: conv2 + conv3 + identity + ReLU as one launch (kernels_c64.hip)
+  void* frag2 = nullptr;
+  void* frag3 = nullptr;
 };
+// fragment blobs of kernels_c64.hip (W2 [64][64][3][3]; W3 [256][64] or null: the plain 3x3)
+void build_c64_fragments(DeviceWeights& dw, const float* W2, const float* W3, void** frag2, void** frag3);
+template <class E>
+void launch_conv3x3_c64(const TensorT<E>& x, const TensorT<E>& y, const TensorT<E>* res, const void* frag2, const void* frag3, const float* scale2, const float* shift2,
+                        const float* scale3, const float* shift3, int act2, hipStream_t s);
 struct ResNet {
   ConvW stem;
   std::vector<std::vector<ResBlock>> layers;
@@ -240,6 +248,7 @@ struct GatedConvW {
   // 64-channel level of a 2-byte model: the whole gate + its 16 x 16 average pool as ONE launch (kernels_gate.hip); null otherwise
   void* fused = nullptr;
   float* fused_bias = nullptr;
+  void* w2_frag = nullptr;      // 2-byte models: w2 (3x3, 64 -> 64) in the halo-tiled kernel's fragment order (kernels_c64.hip)
 };
 void build_gate64_fragments(DeviceWeights& dw, GatedConvW& g, const float* W0, const float* B0, const float* W2, const float* B2, const float* W4, float b4,
                             const float* Wx, const float* Bx);

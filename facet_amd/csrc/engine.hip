@@ -552,6 +552,9 @@ void build_resnet(ResNet& r, DeviceWeights& dw, const WeightStore& ws, const std
       b.c1 = build_conv(dw, ws, bp + ".conv1", bp + ".bn1", false);
       b.c2 = build_conv(dw, ws, bp + ".conv2", bp + ".bn2", false);
       if (bottleneck) b.c3 = build_conv(dw, ws, bp + ".conv3", bp + ".bn3", false);
+      if (bottleneck && dw.prec != PREC_F32 && b.stride == 1 && b.c2.Cin == 64 && b.c2.Cout == 64 && b.c2.KH == 3 && b.c2.KW == 3 && b.c3.Cin == 64 && b.c3.Cout == 256 &&
+          b.c3.KH == 1 && !b.c2.slope && !b.c3.slope)
+        build_c64_fragments(dw, ws.get(bp + ".conv2.weight").data.data(), ws.get(bp + ".conv3.weight").data.data(), &b.frag2, &b.frag3);
       b.has_down = ws.has(bp + ".downsample.0.weight");
       if (b.has_down) b.down = build_conv(dw, ws, bp + ".downsample.0", bp + ".downsample.1", false);
       L.push_back(b);
@@ -622,6 +625,28 @@ TensorT<T> resnet_forward(Ctx& c, const ResNet& r, const Tensor& x, std::vector<
         // torchvision v1.5 / timm: stride sits on the 3x3 (conv2)
         ConvOptsT<T> o1; o1.act = ACT_RELU;
         TensorT<T> a = conv_new(c, b.c1, t, o1);
+        if constexpr (sizeof(T) == 2) {
+          if (b.frag2 && b.frag3 && a.ld == 64 && !getenv("FE_NO_FUSED_C64")) {      // (A/B hook, read per call)
+            // conv2 + bn2 + relu + conv3 + bn3 + identity + relu in one launch: the 64-channel tensor between them stays in registers
+            TensorT<T> tn = c.arena.tensor_t<T>(a.n, a.h, a.w, 256);
+            const double px = (double)a.pixels(), flops = 2.0 * px * (576.0 * 64 + 64.0 * 256);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c.profile) { FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1)); FE_HIP(hipEventRecord(e0, c.stream)); }
+            launch_conv3x3_c64(a, tn, &idt, b.frag2, b.frag3, b.c2.scale, b.c2.shift, b.c3.scale, b.c3.shift, ACT_RELU, c.stream);
+            if (c.profile) {
+              FE_HIP(hipEventRecord(e1, c.stream)); FE_HIP(hipEventSynchronize(e1));
+              float ms = 0.f;
+              FE_HIP(hipEventElapsedTime(&ms, e0, e1));
+              (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+              char nm[128];
+              snprintf(nm, sizeof nm, "%s fused conv3x3 64->64 + 1x1 64->256 + identity M=%d", PrecOf<T>::value == PREC_F16 ? "f16" : "bf16", (int)a.pixels());
+              c.timings.push_back({nm, flops, 2.0 * px * (64 + 256 + 256), ms});
+            }
+            c.flops_accum += flops; c.flops_half += flops;
+            t = tn;
+            continue;
+          }
+        }
         ConvOptsT<T> o2; o2.sh = o2.sw = b.stride; o2.ph = o2.pw = 1; o2.act = ACT_RELU;
         TensorT<T> bb = conv_new(c, b.c2, a, o2);
         ConvOptsT<T> o3; o3.act = ACT_RELU; o3.res = &idt;

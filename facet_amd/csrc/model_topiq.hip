@@ -75,6 +75,10 @@ void build_topiq_head(TopiqModel& m, const WeightStore& ws) {
                                ws.get(g + ".weight_blk.4.bias").data[0], W.data.data(), B.data.data());
     }
     m.gate[i].w2 = build_conv(m.dw, ws, g + ".weight_blk.2", "", true);
+    {      // 2-byte models: the 64 -> 64 3x3 also in the halo-tiled kernel's fragment order (kernels_c64.hip)
+      const HostTensor& W2h = ws.get(g + ".weight_blk.2.weight");
+      if (m.dw.prec != PREC_F32 && W2h.shape == std::vector<int64_t>{64, 64, 3, 3}) build_c64_fragments(m.dw, W2h.data.data(), nullptr, &m.gate[i].w2_frag, nullptr);
+    }
     m.gate[i].w4 = build_conv(m.dw, ws, g + ".weight_blk.4", "", true);
     m.dim_reduce[i] = build_conv(m.dw, ws, "dim_reduce." + std::to_string(i) + ".0", "", true);
     m.sa[i] = build_enc(m.dw, ws, "sa_attn_blks." + std::to_string(i) + ".layers.0", heads);
@@ -228,7 +232,30 @@ void topiq_head_forward(Ctx& c, TopiqModel& m, const std::vector<TensorT<T>>& fe
     ConvOptsT<T> o0; o0.act = m.wblk_act;
     TensorT<T> wa = conv_new(c, g.w0, f, o0);    // = act(weight_blk[0](x2)) with x2 folded in (see build_topiq_head)
     ConvOptsT<T> o2; o2.act = m.wblk_act; o2.ph = o2.pw = 1;
-    TensorT<T> wb = conv_new(c, g.w2, wa, o2);
+    TensorT<T> wb;
+    bool tiled = false;
+    if constexpr (sizeof(T) == 2) {
+      // (a launch loads the 72 KB of weights into every workgroup's LDS: only where the map is large enough to amortise it)
+      if (g.w2_frag && wa.c == 64 && wa.ld == 64 && !g.w2.scale && wa.pixels() >= 131072 && !getenv("FE_NO_FUSED_C64")) {
+        wb = c.arena.tensor_t<T>(wa.n, wa.h, wa.w, 64);
+        const double flops = 2.0 * (double)wa.pixels() * 576.0 * 64;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c.profile) { FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1)); FE_HIP(hipEventRecord(e0, c.stream)); }
+        launch_conv3x3_c64(wa, wb, (const TensorT<T>*)nullptr, g.w2_frag, nullptr, nullptr, g.w2.shift, nullptr, nullptr, m.wblk_act, c.stream);
+        if (c.profile) {
+          FE_HIP(hipEventRecord(e1, c.stream)); FE_HIP(hipEventSynchronize(e1));
+          float ms = 0.f;
+          FE_HIP(hipEventElapsedTime(&ms, e0, e1));
+          (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+          char nm[128];
+          snprintf(nm, sizeof nm, "%s halo-tiled conv3x3 64->64 M=%d", PrecOf<T>::value == PREC_F16 ? "f16" : "bf16", (int)wa.pixels());
+          c.timings.push_back({nm, flops, 2.0 * (double)wa.pixels() * 128, ms});
+        }
+        c.flops_accum += flops; c.flops_half += flops;
+        tiled = true;
+      }
+    }
+    if (!tiled) wb = conv_new(c, g.w2, wa, o2);
     ConvOptsT<T> o4; o4.act = ACT_SIGMOID; o4.ph = o4.pw = 1;
     TensorT<T> wc = conv_new(c, g.w4, wb, o4);
     ConvOptsT<T> og; og.act = m.gate_act; og.gate = &wc;   // act(x1) * weight

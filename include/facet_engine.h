@@ -163,6 +163,13 @@ int fe_op_conv2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, const 
 int fe_op_topiq_gate64(fe_ctx* ctx, const float* x, int n, int h, int w, const float* w0, const float* b0, const float* w2,
                        const float* b2, const float* w4, float b4, const float* wx, const float* bx, int wblk_act,
                        int gate_act, float* y);
+/* test hook of the halo-tiled 3x3 convolution 64 -> 64 (stride 1, padding 1; kernels_c64.hip; 2-byte precisions only): x [n][64][h][w],
+   w2 [64][64][3][3], y = act2(conv(x, w2) * scale2 + shift2) [n][64][h][w]; with w3 [256][64] (then res [n][256][h][w] too, act2 = ReLU):
+   y = relu((w3 . relu(conv * scale2 + shift2)) * scale3 + shift3 + res) [n][256][h][w] - the tail of a ResNet-50 layer1 bottleneck.
+   scale / shift pointers may be null (1 / 0). */
+int fe_op_conv3x3_c64(fe_ctx* ctx, const float* x, int n, int h, int w, const float* w2, const float* scale2,
+                      const float* shift2, int act2, const float* w3, const float* scale3, const float* shift3,
+                      const float* res, float* y);
 int fe_op_maxpool2d(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int k, int stride, int pad,
                     int ceil_mode, float* y);
 int fe_op_bilinear(fe_ctx* ctx, const float* x, int n, int c, int h, int w, int ho, int wo, float* y);
