@@ -87,6 +87,7 @@ SIGNATURES = {
     "fe_set_conv_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "fe_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int] * 12 + [_f32p]),
     "fe_topiq_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "fe_topiq_f32_below": (C.c_int, [C.c_void_p, C.c_longlong]),
     "fe_topiq_feature_shape": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "fe_ensemble_select": (C.c_int, [C.c_void_p, C.c_int]),
     "fe_ensemble_score_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -432,6 +433,10 @@ class Engine:
     def topiq_configure(self, gate_act="gelu", weight_blk_act="gelu"):
         """Activations of pyiqa's GatedConv used by the NEXT load_weights(FE_MODEL_TOPIQ): 'relu' | 'gelu' | 'softplus'."""
         self._ck(self.lib.fe_topiq_configure(self.h, ACT[gate_act], ACT[weight_blk_act]))
+
+    def topiq_f32_below(self, pixels):
+        """2-byte TOPIQ: images with fewer than `pixels` pixels are scored on the model's fp32 weights (0 = never, the default)."""
+        self._ck(self.lib.fe_topiq_f32_below(self.h, int(pixels)))
 
     def topiq_feature_shape(self, h, w, level):
         """(channels, height, width) of pyramid level `level` for h x w images, as the engine computes it (conv / pool output

@@ -320,6 +320,13 @@ int fe_model_precision(fe_ctx* ctx, int model) {
   return -1;
 }
 
+int fe_topiq_f32_below(fe_ctx* ctx, long long pixels) {
+  FE_API_BEGIN(ctx)
+  FE_CHECK(pixels >= 0, "topiq_f32_below: negative pixel count");
+  ctx->c.topiq_f32_below = (size_t)pixels;
+  FE_API_END(ctx)
+}
+
 int fe_topiq_configure(fe_ctx* ctx, int gate_act, int weight_blk_act) {
   FE_API_BEGIN(ctx)
   auto ok = [](int a) { return a == FE_ACT_RELU || a == FE_ACT_GELU || a == FE_ACT_SOFTPLUS; };
@@ -769,9 +776,19 @@ static void topiq_backbone_chunk(fe_ctx* ctx, const uint8_t* d_rgb, int nb, int 
   resnet_forward<T>(C, ctx->c.topiq->backbone, x, &feats, ctx->c.topiq->dw.res32);      // RES32: fp32 skip stream in the backbone
 }
 // backbone + head of one micro-batch in the precision the model was committed under; scores are fp32 either way
+// fe_topiq_f32_below: images with fewer pixels run on the model's fp32 weights even when it was committed under a 2-byte precision.
+// With a few dozen tokens per pyramid level the rounding noise of a 2-byte pass is not averaged down (fp16 TOPIQ on 33 x 500 and
+// 97 x 131 inputs: 4e-4 .. 1.2e-3 from the oracle, against <= 6e-4 from 512 x 512 up, tests/test_precision_policy_gpu.py), and such an
+// image costs under a sixteenth of a 1024 x 1024 one. The PARITY policy (facet_amd/precision.py) sets 256 x 256; the default is 0.
+// (Every 2-byte model keeps its fp32 weights: pack_conv only drops them for half_only models, which TOPIQ is not.)
 static void topiq_chunk_score(fe_ctx* ctx, const uint8_t* d_in, int nb, int h, int w, float* d_scores) {
   Ctx& C = ctx->c;
-  if (C.topiq->dw.prec == PREC_BF16) {
+  const bool small = (size_t)h * (size_t)w < C.topiq_f32_below && !C.topiq->dw.half_only && !C.topiq->dw.res32;
+  if (C.topiq->dw.prec != PREC_F32 && small) {
+    std::vector<Tensor> feats;
+    topiq_backbone_chunk<float>(ctx, d_in, nb, h, w, feats);
+    topiq_head_forward<float>(C, *C.topiq, feats, d_scores);
+  } else if (C.topiq->dw.prec == PREC_BF16) {
     std::vector<TensorH> feats;
     topiq_backbone_chunk<bf16>(ctx, d_in, nb, h, w, feats);
     topiq_head_forward<bf16>(C, *C.topiq, feats, d_scores);

@@ -225,6 +225,7 @@ struct Ctx {
   bool split3 = false;        // FE_PRECISION_SPLIT3 of the next commit
   // TOPIQ GatedConv activations picked up by the next fe_weights_commit(FE_MODEL_TOPIQ) (fe_topiq_configure)
   int topiq_gate_act = ACT_GELU, topiq_wblk_act = ACT_GELU;
+  size_t topiq_f32_below = 0;   // 2-byte TOPIQ: images with fewer pixels run on the model's fp32 weights (fe_topiq_f32_below; 0 = never)
 
   std::map<std::tuple<int, int, int>, ResizeCoeffsDev> resize_cache;  // (in, out, filter) -> device tables
   WeightStore staging[8];

@@ -188,6 +188,10 @@ int fe_bench_conv(fe_ctx* ctx, int n, int h, int w, int cin, int cout, int k, in
  * Default GELU / GELU. Activations carry no parameters, so a checkpoint cannot tell which a pyiqa release used (pyiqa is not
  * vendored in the reference, models/pyiqa_scorer.py:33-39,108-111): the choice is a load-time option [DEP-KNOWLEDGE]. */
 int fe_topiq_configure(fe_ctx* ctx, int gate_act, int weight_blk_act);
+/* A TOPIQ model committed under a 2-byte precision scores images of fewer than `pixels` pixels on its fp32 weights (0, the default:
+ * never). Small images give the head a few dozen tokens per level, too few to average the 2-byte rounding noise below the 1e-3 gate;
+ * the PARITY precision policy (facet_amd/precision.py) sets 65536. */
+int fe_topiq_f32_below(fe_ctx* ctx, long long pixels);
 /* dims = {channels, height, width} of pyramid level `level` for h x w inputs (after the > 1024 LANCZOS cap of
  * models/pyiqa_scorer.py:131-153): the size of one image's block in fe_topiq_features' output. No context needed. */
 int fe_topiq_feature_shape(int h, int w, int level, int dims[3]);

@@ -100,13 +100,13 @@ def test_integer_data_is_exact_in_both_forms(eng2):
 
 
 def test_topiq_scores_with_and_without_the_fused_bottleneck_tails():
-    """Whole fp16 TOPIQ on 200 x 264 images (layer1 at 50 x 66: partial tiles): scores with the chained kernel, with the three-launch
+    """Whole fp16 TOPIQ on 264 x 328 images (layer1 at 66 x 82: partial tiles): scores with the chained kernel, with the three-launch
     form (FE_NO_FUSED_C64) and of the fp32 engine agree within the 1e-3 gate."""
     from facet_amd import Engine
     from facet_amd._lib import FE_MODEL_TOPIQ
     from facet_amd.weights import synthetic_images, synthetic_state_dict
     sd = synthetic_state_dict("topiq", 13)
-    imgs = synthetic_images(9, 3, 200, 264)
+    imgs = synthetic_images(9, 3, 264, 328)
     out = {}
     for name, prec, env in (("f32", "f32", None), ("fused", "f16", None), ("unfused", "f16", "1")):
         os.environ.pop("FE_NO_FUSED_C64", None)
