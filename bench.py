@@ -225,6 +225,18 @@ def vlm_sub(dev_index, progress, layers=4):
                                  "decode_frac_of_hbm_peak": round(wbytes / t_dec / 1e6 / 8000, 3),
                                  "decode_ms_per_step_28_layers_extrapolated": round(t_full, 2),
                                  "decode_tokens_per_s_28_layers_extrapolated": round(B / t_full * 1e3)}
+        # the fields every sub line carries: value = decode tokens/s at configs[4]'s batch (measured layers only: NOT the 28-layer model);
+        # roofline of the dominant kernel of a decode step - the weight stream (vlm_gemm32_kernel / vlm_gemv_kernel), HBM-bound
+        b32 = out["batch_32"]
+        out["value"] = round(32 / b32["decode_ms_per_step_measured"] * 1e3, 1)
+        out["unit"] = f"decode tokens/s at batch 32 through {layers} of 28 decoder layers + the full lm_head"
+        out["dtype"] = "bf16"
+        out["config"] = {"workload": "Qwen2.5-VL-7B geometry (BASELINE configs[4], models/vlm_tagger.py): 32 sequences x 512 prompt tokens, greedy decode; seeded weights; "
+                                     f"{layers} of 28 decoder layers + lm_head (152064 x 3584) measured, the 28-layer figures beside them are extrapolated",
+                         "batch": 32, "prompt_tokens": 512}
+        out["roofline"] = {"bound": "hbm", "achieved": b32["decode_weight_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": round(b32["decode_weight_GBps"] / 8000.0, 4),
+                           "traffic": None, "kernel": "vlm_gemm32_kernel (weight-streaming v_mfma_f32_32x32x16_bf16, 5..32 sequences) / vlm_gemv_kernel (<= 4)",
+                           "note": "achieved = bf16 weight bytes of the measured layers + lm_head per decode step / step time (whole step, all launches)"}
         progress(f"sub.vlm_tagger: vision {out['vision_tower']['images_per_s']} images/s, decode {out['batch_32']['decode_ms_per_step_measured']} ms/step at batch 32")
         return out
     finally:
