@@ -138,6 +138,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- the 3x3: 36 K-steps (tap x 16 channels), two pixel tiles x two channel halves per wave --------------------------------------
     const int qb = wave * 64 + r;
+    // the lane's two output pixels (its columns of the two pixel tiles)
+    bool okn[2]; size_t pixn[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int q = qb + n * 32;
+      const int oy = y0 + (q >> 4), ocol = q & 15, ox = x0 + ocol;
+      okn[n] = ocol < 14 && oy < p.H && ox < p.W;
+      pixn[n] = ((size_t)b * p.H + (okn[n] ? oy : y0)) * p.W + (okn[n] ? ox : x0);
+    }
+    // chained form: the identity and the result cross HBM as whole pixel rows (16 bytes per lane, 16 lanes = 256 contiguous bytes of one
+    // pixel) through a wave-private LDS image, not as the accumulator layout's 8-byte quads: as quads every store instruction touched
+    // 32 cache lines 16 bytes at a time and the launch sat at 3.5 TB/s. Piece i (of 8) of a pixel tile's 32 pixels x 128 channels: pixel lane / 16 + 4 i, 16 bytes at lane % 16.
+    const int pc_part = lane & 15;
+    bool pc_ok[16]; size_t pc_pix[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = i >> 3, px = (lane >> 4) + 4 * (i & 7), q = wave * 64 + n * 32 + px;
+      const int oy = y0 + (q >> 4), ocol = q & 15, ox = x0 + ocol;
+      pc_ok[i] = ocol < 14 && oy < p.H && ox < p.W;
+      pc_pix[i] = ((size_t)b * p.H + (pc_ok[i] ? oy : y0)) * p.W + (pc_ok[i] ? ox : x0);
+    }
+    fe_v4f idr[2][8];      // the identity rows of one half (128 channels) of one pixel tile, and of the one after it
+    auto fetch_identity = [&](const int n, const int half, fe_v4f (&dst)[8]) __attribute__((always_inline)) {
+      if constexpr (CHAIN) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const fe_v4f*>(p.res + pc_pix[n * 8 + i] * p.ldr + half * 128 + pc_part * 8);
+      }
+    };
+    fetch_identity(0, 0, idr[0]);      // lands behind the matrix loop
     const char* const bB = sPatch + qb * C64_PITCH + h * 16;
     const char* const bA = sW2 + lane * 16;
     fe_f32x16 acc[2][2];
@@ -166,17 +195,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
     __syncthreads();      // every wave is done with this patch
-    store_patch();        // the next one (no-op data past the last tile)
 
     // ---- epilogue ----------------------------------------------------------------------------------------------------------------------
+    if constexpr (!CHAIN) {
+      store_patch();        // the next patch (stale data past the last tile)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int q = qb + n * 32;
-      const int oy = y0 + (q >> 4), ocol = q & 15, ox = x0 + ocol;
-      const bool ok = ocol < 14 && oy < p.H && ox < p.W;
-      const size_t pix = ((size_t)b * p.H + (ok ? oy : y0)) * p.W + (ok ? ox : x0);
-      if constexpr (!CHAIN) {
-        E* const yr = p.y + pix * p.ldy;
+      for (int n = 0; n < 2; ++n) {
+        const bool ok = okn[n];
+        E* const yr = p.y + pixn[n] * p.ldy;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -186,14 +212,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const c64_f2 hi = c64_act2<A2>(__builtin_elementwise_fma(c64_f2{acc[n][mt][4 * g + 2], acc[n][mt][4 * g + 3]}, c64_f2{s.z, s.w}, c64_f2{f.z, f.w}), p.act2);
             if (ok) *reinterpret_cast<uint2*>(yr + mt * 32 + 8 * g + 4 * h) = make_uint2(fe_pack2(tag, lo.x, lo.y), fe_pack2(tag, hi.x, hi.y));
           }
-      } else {
-        // the identity's 32 quads of this pixel, requested before the expand's matrix instructions
-        const E* const rr = p.res + pix * p.ldr + 4 * h;
-        uint2 idt[8][4];
+      }
+    } else {
+      // the patch buffer is free until the next patch is stored: 32 pixels x (256 + 16) bytes per wave
+      constexpr int SP = 272;
+      char* const stg = sPatch + wave * (32 * SP);
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) idt[m][g] = *reinterpret_cast<const uint2*>(rr + m * 32 + 8 * g);
+      for (int n = 0; n < 2; ++n) {
         // mid = relu(acc * scale2 + shift2) as the B fragments of the expand: step s = (mt, half) holds quads 2 half, 2 half + 1 of mt
         fe_v4f bq[4];
 #pragma unroll
@@ -211,26 +236,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             bq[mt * 2 + half] = fe_v4f{__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3])};
           }
-        E* const yr = p.y + pix * p.ldy + 4 * h;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          fe_f32x16 a3;
+        for (int hf = 0; hf < 2; ++hf) {      // output channels 128 hf .. + 128
+          const int cur = (n * 2 + hf) & 1;
+          // identity rows -> LDS (row layout); the next half's rows are requested now
 #pragma unroll
-          for (int e = 0; e < 16; ++e) a3[e] = 0.f;
+          for (int i = 0; i < 8; ++i) *reinterpret_cast<fe_v4f*>(stg + ((lane >> 4) + 4 * i) * SP + pc_part * 16) = idr[cur][i];
+          if (hf == 0) fetch_identity(n, 1, idr[cur ^ 1]);
+          else if (n == 0) fetch_identity(1, 0, idr[cur ^ 1]);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) a3 = fe_mfma16(tag, *reinterpret_cast<const fe_v4f*>(sW3 + (m * 4 + s) * 1024 + lane * 16), bq[s], a3);
+          for (int mm = 0; mm < 4; ++mm) {
+            const int m = hf * 4 + mm;
+            fe_f32x16 a3;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 s = *reinterpret_cast<const float4*>(sSS + 128 + m * 32 + 8 * g + 4 * h);
-            const float4 f = *reinterpret_cast<const float4*>(sSS + 384 + m * 32 + 8 * g + 4 * h);
-            float i0, i1, i2, i3;
-            fe_unpack2(tag, idt[m][g].x, i0, i1); fe_unpack2(tag, idt[m][g].y, i2, i3);
-            const c64_f2 lo = c64_act2<ACT_RELU>(__builtin_elementwise_fma(c64_f2{a3[4 * g + 0], a3[4 * g + 1]}, c64_f2{s.x, s.y}, c64_f2{f.x, f.y}) + c64_f2{i0, i1}, 0);
-            const c64_f2 hi = c64_act2<ACT_RELU>(__builtin_elementwise_fma(c64_f2{a3[4 * g + 2], a3[4 * g + 3]}, c64_f2{s.z, s.w}, c64_f2{f.z, f.w}) + c64_f2{i2, i3}, 0);
-            if (ok) *reinterpret_cast<uint2*>(yr + m * 32 + 8 * g) = make_uint2(fe_pack2(tag, lo.x, lo.y), fe_pack2(tag, hi.x, hi.y));
+            for (int e = 0; e < 16; ++e) a3[e] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) a3 = fe_mfma16(tag, *reinterpret_cast<const fe_v4f*>(sW3 + (m * 4 + st) * 1024 + lane * 16), bq[st], a3);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 s = *reinterpret_cast<const float4*>(sSS + 128 + m * 32 + 8 * g + 4 * h);
+              const float4 f = *reinterpret_cast<const float4*>(sSS + 384 + m * 32 + 8 * g + 4 * h);
+              uint2* const cell = reinterpret_cast<uint2*>(stg + r * SP + (mm * 32 + 8 * g + 4 * h) * 2);      // the lane's quad of its pixel
+              const uint2 id = *cell;
+              float i0, i1, i2, i3;
+              fe_unpack2(tag, id.x, i0, i1); fe_unpack2(tag, id.y, i2, i3);
+              const c64_f2 lo = c64_act2<ACT_RELU>(__builtin_elementwise_fma(c64_f2{a3[4 * g + 0], a3[4 * g + 1]}, c64_f2{s.x, s.y}, c64_f2{f.x, f.y}) + c64_f2{i0, i1}, 0);
+              const c64_f2 hi = c64_act2<ACT_RELU>(__builtin_elementwise_fma(c64_f2{a3[4 * g + 2], a3[4 * g + 3]}, c64_f2{s.z, s.w}, c64_f2{f.z, f.w}) + c64_f2{i2, i3}, 0);
+              *cell = make_uint2(fe_pack2(tag, lo.x, lo.y), fe_pack2(tag, hi.x, hi.y));
+            }
+          }
+          // result rows: LDS -> HBM, 256 contiguous bytes per pixel
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const fe_v4f o = *reinterpret_cast<const fe_v4f*>(stg + ((lane >> 4) + 4 * i) * SP + pc_part * 16);
+            if (pc_ok[n * 8 + i]) *reinterpret_cast<fe_v4f*>(p.y + pc_pix[n * 8 + i] * p.ldy + hf * 128 + pc_part * 8) = o;
           }
         }
       }
+      __syncthreads();      // every wave is done with its image in the patch buffer
+      store_patch();        // the next patch (stale data past the last tile)
     }
     __syncthreads();      // the next patch is in LDS
   }
@@ -266,7 +310,7 @@ void launch_conv3x3_c64(const TensorT<E>& x, const TensorT<E>& y, const TensorT<
   const bool chain = frag3 != nullptr;
   FE_CHECK(x.c == 64 && y.n == x.n && y.h == x.h && y.w == x.w && y.c == (chain ? 256 : 64) && x.ld % 8 == 0 && y.ld % 4 == 0, "conv3x3_c64: %dx%dx%d -> %dx%dx%d", x.h, x.w, x.c,
            y.h, y.w, y.c);
-  FE_CHECK(!chain || (res && res->c == 256 && res->pixels() == y.pixels() && res->ld % 4 == 0 && act2 == ACT_RELU), "conv3x3_c64: the chained form needs the identity and ReLU");
+  FE_CHECK(!chain || (res && res->c == 256 && res->pixels() == y.pixels() && res->ld % 8 == 0 && y.ld % 8 == 0 && act2 == ACT_RELU), "conv3x3_c64: the chained form needs the identity (16-byte rows) and ReLU");
   FE_CHECK(chain || (act2 >= ACT_NONE && act2 <= ACT_SOFTPLUS && act2 != ACT_PRELU), "conv3x3_c64: activation %d", act2);
   FE_CHECK((size_t)x.n * x.h * x.w * (size_t)(x.ld > y.ld ? x.ld : y.ld) < (1ull << 40), "conv3x3_c64: tensor too large");
   C64Params<E> p{};
