@@ -76,7 +76,8 @@ def test_conv_exact_integers(engine):
 
 @pytest.mark.parametrize("shape,k,s,p,ceil", [((2, 64, 37, 41), 3, 2, 1, False), ((1, 16, 15, 15), 2, 2, 0, True),
                                               ((1, 16, 14, 14), 2, 2, 0, True), ((1, 1, 224, 224), 3, 2, 1, False),
-                                              ((2, 3, 7, 9), 2, 2, 0, True)])
+                                              ((2, 3, 7, 9), 2, 2, 0, True), ((1, 8, 9, 10), 3, 1, 1, False), ((1, 4, 10, 10), 3, 2, 0, True),
+                                              ((3, 128, 20, 24), 3, 2, 1, False)])
 def test_maxpool(engine, shape, k, s, p, ceil):
     x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
     ref = F.max_pool2d(x, k, s, p, ceil_mode=ceil)
