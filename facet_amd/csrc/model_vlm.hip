@@ -335,49 +335,96 @@ static void vlm_gemv(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, TO* 
   c.flops_accum += 2.0 * M * (double)w.Cin * w.Cout;
 }
 // ---- decode GEMM for 5 .. 32 sequences: the weight rows are the A operand of v_mfma_f32_32x32x16_bf16 (32 output columns per wave),
-// the activation rows the B operand (batch rows padded to 32 with zeros), K split over the workgroups of grid.y and the four waves of
-// each; every weight byte is read once per step. Inside a 64-element block of K lane (r, h) owns elements 32 h .. 32 h + 31 of its row
-// (64 contiguous bytes = four 16-byte loads = the fragments of four matrix instructions; the contraction order is free as long as both
-// operands use it). Partial sums [split][M][N] in fp32, added in a fixed order by the finishing kernel (no atomics: the same token ids
-// on every run).
+// the activation rows the B operand (batch rows padded to 32 with zeros); every weight byte is read once per step. A workgroup takes
+// FOUR column tiles (one per wave) over one K range (grid.y = the K split), in stages of 128 K-elements.
+//   * Weights reach the matrix fragments through a wave-private LDS image: the fragment layout wants 16 bytes of each of 32 rows per
+//     load instruction - 64 sectors touched for 1 KiB, every 64-byte sector fetched four times from L2 by the four instructions that share
+//     it (measured: 1.6 TB/s with nontemporal loads, 2.1 with cached ones). The loads instead take 4 rows x 256 contiguous bytes per
+//     instruction (whole sectors, once), the registers go to LDS (16-byte slots XORed with the row number: conflict-free for the writes'
+//     8-lane groups and the fragment reads' 16-lane groups) and come back as fragments. Loads run one stage ahead in registers.
+//   * The activation slice of a stage (32 rows x 256 B) is staged once per workgroup, double-buffered, for all four waves - fetched per
+//     wave from L2 it was half of the load traffic of a "weight-streaming" kernel.
+// Inside a 64-element block of K lane (r, h) owns elements 32 h .. 32 h + 31 of its row (four fragments; the contraction order is free as
+// long as both operands use it). Partial sums [split][M][N] in fp32, added in a fixed order by the finishing kernel (no atomics: the
+// same token ids on every run).
+constexpr int VLM_G32_XP = 272;      // bytes per staged activation row: 128 elements + 16 (conflict-free 16-byte reads at stride 1 row)
+// (w2 / part2: a second weight matrix of the same shape on the same activations - the gate and up projections of the MLP as ONE launch:
+// workgroup columns [cols1, 2 cols1) take it)
 __global__ __launch_bounds__(256) void vlm_gemm32_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w, int ldw, float* __restrict__ part, int M, int N,
-                                                         int K, int kblocks_per_wg) {
-  __shared__ float red[3][32 * 33];
+                                                         int K, int stages_per_wg, const bf16* __restrict__ w2, float* __restrict__ part2, int cols1) {
+  __shared__ __attribute__((aligned(16))) char ws[4][32 * 256];
+  __shared__ __attribute__((aligned(16))) char xs[2][32 * VLM_G32_XP];
   const bf16* const tag = nullptr;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.x * 32;
-  const int nr = n0 + r < N ? n0 + r : N - 1;               // rows past N are computed on a valid row and dropped
-  const bf16* wr = w + (size_t)nr * ldw + 32 * h;
-  const bf16* xr = x + (size_t)(r < M ? r : 0) * ldx + 32 * h;
-  const bool xok = r < M;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+  const int ntiles = (N + 31) / 32;
+  int bx = blockIdx.x;
+  if (bx >= cols1) { bx -= cols1; w = w2; part = part2; }
+  const int nt = min(bx * 4 + wave, ntiles - 1);      // a workgroup's waves past the last tile repeat it (and do not store)
+  const int n0 = nt * 32;
+  const int nst = K / 128;
+  const int s0 = blockIdx.y * stages_per_wg, s1 = min(s0 + stages_per_wg, nst);
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  // weight piece i of a stage: row 4 i + lane / 16 of the tile, 16 bytes at 16 (lane % 16) of the row's 256
+  const int wrow = lane >> 4, wpc = lane & 15;
+  const bf16* wsrc[8];
+  int wdst[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = 4 * i + wrow, nr = min(n0 + row, N - 1);      // rows past N: a valid row, dropped at the store
+    wsrc[i] = w + (size_t)nr * ldw + wpc * 8;
+    wdst[i] = row * 256 + ((wpc ^ (row & 15)) << 4);
+  }
+  auto fetch_w = [&](const int st, v4u (&dst)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const v4u*>(wsrc[i] + (size_t)st * 128);
+  };
+  // activation piece i (of 2) of a stage: row (t + 256 i) / 16, 16 bytes at 16 ((t + 256 i) % 16)
+  auto stage_x = [&](const int st, char* dst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = t + 256 * i, row = p >> 4, col = (p & 15) * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (row < M) v = *reinterpret_cast<const uint4*>(x + (size_t)row * ldx + (size_t)st * 128 + col);
+      *reinterpret_cast<uint4*>(dst + row * VLM_G32_XP + col * 2) = v;
+    }
+  };
   fe_f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  const int kb0 = blockIdx.y * kblocks_per_wg, kb1 = min(kb0 + kblocks_per_wg, K / 64);
-  for (int kb = kb0 + wave; kb < kb1; kb += 4) {
-    const int k = kb * 64;
-    v4u a[4];
-    uint4 b[4];
+  v4u wr[2][8];
+  char* const wl = ws[wave];
+  if (s0 < s1) { fetch_w(s0, wr[0]); stage_x(s0, xs[0]); }
+  __syncthreads();
+  // (unrolled by two so the register sets and the activation buffers are compile-time choices)
+  for (int st = s0; st < s1; st += 2) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(wr + k + 8 * s));
+    for (int u = 0; u < 2; ++u) {
+      const int cur = st + u;
+      if (cur < s1) {
+        if (cur + 1 < s1) fetch_w(cur + 1, wr[u ^ 1]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b[s] = xok ? *reinterpret_cast<const uint4*>(xr + k + 8 * s) : make_uint4(0u, 0u, 0u, 0u);
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<v4u*>(wl + wdst[i]) = wr[u][i];
+        if (cur + 1 < s1) stage_x(cur + 1, xs[u ^ 1]);      // the other buffer: its readers passed the barrier one stage ago
+        const char* const xb = xs[u] + r * VLM_G32_XP + 64 * h;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc = fe_mfma16(tag, __builtin_bit_cast(fe_v4f, a[s]), __builtin_bit_cast(fe_v4f, b[s]), acc);
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int pc = kb * 8 + h * 4 + q;      // the 16-byte piece of the row this fragment is
+            const fe_v4f a = *reinterpret_cast<const fe_v4f*>(wl + r * 256 + ((pc ^ (r & 15)) << 4));
+            acc = fe_mfma16(tag, a, *reinterpret_cast<const fe_v4f*>(xb + kb * 128 + 16 * q), acc);
+          }
+      }
+      __syncthreads();
+    }
   }
   // acc: lane (r, h) holds column m = r (batch row) of the 32 x 32 tile, rows n = (e & 3) + 8 (e >> 2) + 4 h
-  if (wave > 0) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) red[wave - 1][((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = acc[e];
-  }
-  __syncthreads();
-  if (wave == 0 && r < M) {
+  if (bx * 4 + wave < ntiles && r < M) {
     float* out = part + ((size_t)blockIdx.y * M + r) * N + n0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int nn = (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (n0 + nn < N) out[nn] = (acc[e] + red[0][nn * 33 + r]) + (red[1][nn * 33 + r] + red[2][nn * 33 + r]);
+      if (n0 + nn < N) out[nn] = acc[e];
     }
   }
 }
@@ -391,29 +438,102 @@ __global__ void vlm_gemm32_finish_kernel(const float* __restrict__ part, int spl
   for (int k = 0; k < splits; ++k) s += part[((size_t)k * M + m) * N + n];
   stf(y + (size_t)m * ldy + n, s + v);
 }
+// launches the partial products of y = x W^T into `part` ([splits][M][N] fp32, taken from the arena: the CALLER rewinds); returns the split count
+static int vlm_gemm32_partials(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float** part, const ConvW* w2 = nullptr, float** part2 = nullptr) {
+  const int K = w.CinPadH, N = w.Cout;
+  FE_CHECK(w.wh && w.hprec == PREC_BF16 && !w.scale && K % 128 == 0 && w.KpH % 8 == 0 && ldx % 8 == 0 && M >= 1 && M <= 32, "vlm_gemm32: unsupported layer");
+  FE_CHECK(!w2 || (w2->wh && w2->hprec == PREC_BF16 && !w2->scale && w2->CinPadH == K && w2->Cout == N && w2->KpH == w.KpH && part2), "vlm_gemm32: the paired matrix differs in shape");
+  const int ntiles = (N + 31) / 32, cols = (ntiles + 3) / 4, nst = K / 128, allcols = w2 ? 2 * cols : cols;
+  // ~3 workgroups per CU stream from all of HBM; the partial sums of a split cost 4 M N bytes each way: no more splits than that needs,
+  // and at least 4 stages per workgroup
+  int splits = std::max(1, std::min(nst / 4, (768 + allcols - 1) / allcols));
+  const int per = (nst + splits - 1) / splits;
+  splits = (nst + per - 1) / per;
+  *part = c.arena.array<float>((size_t)splits * M * N);
+  if (w2) *part2 = c.arena.array<float>((size_t)splits * M * N);
+  hipLaunchKernelGGL(vlm_gemm32_kernel, dim3(allcols, splits), dim3(256), 0, c.stream, x, ldx, (const bf16*)w.wh, w.KpH, *part, M, N, K, per,
+                     w2 ? (const bf16*)w2->wh : (const bf16*)nullptr, w2 ? *part2 : (float*)nullptr, cols);
+  FE_HIP(hipGetLastError());
+  const double fl = 2.0 * M * (double)w.Cin * N * (w2 ? 2 : 1);
+  c.flops_accum += fl; c.flops_half += fl;
+  return splits;
+}
 template <class TO>
 static void vlm_gemm32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, TO* y, int ldy) {
-  const int K = w.CinPadH, N = w.Cout;
-  FE_CHECK(w.wh && w.hprec == PREC_BF16 && !w.scale && K % 64 == 0 && w.KpH % 8 == 0 && ldx % 8 == 0 && M >= 1 && M <= 32, "vlm_gemm32: unsupported layer");
-  const int ntiles = (N + 31) / 32, kblocks = K / 64;
-  int splits = std::max(1, std::min(kblocks / 4, (2048 + ntiles * 4 - 1) / (ntiles * 4)));      // enough waves to stream from all of HBM: >= ~2048
-  const int per = (kblocks + splits - 1) / splits;
-  splits = (kblocks + per - 1) / per;
   const size_t mark = c.arena.mark();
-  float* part = c.arena.array<float>((size_t)splits * M * N);
-  hipLaunchKernelGGL(vlm_gemm32_kernel, dim3(ntiles, splits), dim3(256), 0, c.stream, x, ldx, (const bf16*)w.wh, w.KpH, part, M, N, K, per);
+  float* part = nullptr;
+  const int splits = vlm_gemm32_partials(c, w, x, ldx, M, &part), N = w.Cout;
   hipLaunchKernelGGL((vlm_gemm32_finish_kernel<TO>), dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, c.stream, (const float*)part, splits, M, N,
                      (const float*)w.shift, y, ldy);
   FE_HIP(hipGetLastError());
   c.arena.rewind(mark);
-  c.flops_accum += 2.0 * M * (double)w.Cin * N; c.flops_half += 2.0 * M * (double)w.Cin * N;
+}
+static bool vlm_uses_gemm32(const ConvW& w, int M) {
+  static const bool no32 = getenv("FE_VLM_NO_GEMM32") != nullptr;      // A/B hook
+  return M > 3 && M <= 32 && w.CinPadH % 128 == 0 && !no32;      // measured: 4 sequences 0.94 ms / step here, 1.02 through the GEMV
+}
+// Finishing passes of the decode GEMM fused with what follows them (a 32-sequence step was ~30 launches per layer of which the 5-us ones -
+// split sums, residual sums, norms, the gate product - were a quarter of the time). One workgroup per sequence row.
+//   x = bf16(x + bf16(sum_k part + bias)); n = RMSNorm(x) * w   (w == nullptr: the sum only)
+__global__ __launch_bounds__(1024) void vlm_finish_add_rmsnorm_kernel(const float* __restrict__ part, int splits, int M, int d, const float* __restrict__ bias, bf16* __restrict__ x,
+                                                                     const bf16* __restrict__ w, bf16* __restrict__ n, float eps) {
+  __shared__ float red[16];
+  const int row = blockIdx.x, t = threadIdx.x;      // 1024 threads: with 256 a row of 25 splits was 100 dependent-latency loads per thread
+  bf16* const xr = x + (size_t)row * d;
+  float ss = 0.f;
+  for (int i = t * 4; i < d; i += 4096) {
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // eight loads in flight, added in split order (the order of the stand-alone finishing pass: same bits)
+    for (int k0 = 0; k0 < splits; k0 += 8) {
+      float4 p4[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        p4[j] = k0 + j < splits ? *reinterpret_cast<const float4*>(part + ((size_t)(k0 + j) * M + row) * d + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < splits) { sum.x += p4[j].x; sum.y += p4[j].y; sum.z += p4[j].z; sum.w += p4[j].w; }
+    }
+    if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + i); sum.x += b4.x; sum.y += b4.y; sum.z += b4.z; sum.w += b4.w; }
+    const float4 a = ld4(xr + i);
+    // the projection's output is a bf16 tensor, and so is the residual stream
+    const float4 v = make_float4((float)(bf16)(a.x + (float)(bf16)sum.x), (float)(bf16)(a.y + (float)(bf16)sum.y), (float)(bf16)(a.z + (float)(bf16)sum.z),
+                                 (float)(bf16)(a.w + (float)(bf16)sum.w));
+    st4(xr + i, v);
+    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (!w) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if ((t & 63) == 0) red[t >> 6] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tot += red[k];
+  const float rs = rsqrtf(tot / (float)d + eps);
+  bf16* const nr = n + (size_t)row * d;
+  for (int i = t * 4; i < d; i += 4096) {
+    const float4 v = ld4(xr + i), g = ld4(w + i);      // (this thread's own stores of the first loop)
+    st4(nr + i, make_float4(g.x * (float)(bf16)(v.x * rs), g.y * (float)(bf16)(v.y * rs), g.z * (float)(bf16)(v.z * rs), g.w * (float)(bf16)(v.w * rs)));
+  }
+}
+//   h = bf16(silu(bf16(sum_k pg))) * bf16(sum_k pu)   (the two projections of the SwiGLU MLP, same split count)
+__global__ void vlm_finish_silu_mul_kernel(const float* __restrict__ pg, const float* __restrict__ pu, int splits, size_t mn4, bf16* __restrict__ hout) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), u = g;
+    for (int k = 0; k < splits; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(pg + (k * mn4 + i) * 4), b = *reinterpret_cast<const float4*>(pu + (k * mn4 + i) * 4);
+      g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w;
+      u.x += b.x; u.y += b.y; u.z += b.z; u.w += b.w;
+    }
+    auto f = [](float x, float y) { x = (float)(bf16)x; y = (float)(bf16)y; return (float)(bf16)(x / (1.f + expf(-x))) * y; };
+    st4(hout + 4 * i, make_float4(f(g.x, u.x), f(g.y, u.y), f(g.z, u.z), f(g.w, u.w)));
+  }
 }
 // y = x W^T (+ b) in bf16 for any row count: the streaming GEMV for up to 4 rows, the weight-streaming matrix-core GEMM up to 32, the
 // shared layer wrapper above that
 static void vlm_linear(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, bf16* y, int ldy) {
-  static const bool no32 = getenv("FE_VLM_NO_GEMM32") != nullptr;      // A/B hook
-  if (M <= 4) vlm_gemv(c, w, x, ldx, M, y, ldy);
-  else if (M <= 32 && w.CinPadH % 64 == 0 && !no32) vlm_gemm32(c, w, x, ldx, M, y, ldy);
+  if (M <= 4 && !vlm_uses_gemm32(w, M)) vlm_gemv(c, w, x, ldx, M, y, ldy);
+  else if (vlm_uses_gemm32(w, M)) vlm_gemm32(c, w, x, ldx, M, y, ldy);
   else linear_forward(c, w, x, ldx, M, y, ldy, ACT_NONE);
 }
 
@@ -496,70 +616,115 @@ __global__ void vlm_argmax_final_kernel(const float* __restrict__ pv, const int*
   if (t == 0) next[b] = j;
 }
 
-// Decode attention with the keys split over workgroups (one (sequence, head) alone kept 28 of 256 CUs busy for 43 us per layer): block
-// (bh, s) takes keys [256 s, 256 s + 256), writes its unnormalised output, running maximum and sum; vlm_attn_combine_kernel merges the
-// chunks of a head. Lk by value or, for graph replay, from device memory (then the grid covers the whole cache and chunks past Lk exit).
-constexpr int VLM_DEC_CHUNK = 256;
-__global__ __launch_bounds__(256) void vlm_attn_decode_split_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kc, const bf16* __restrict__ vc, float* __restrict__ po,
-                                                                    float* __restrict__ pm, float* __restrict__ pl, int nh, int nkv, int Lk, int max_seq, float scale,
-                                                                    const int* __restrict__ len_dev, int nsplit) {
-  __shared__ float sc[VLM_DEC_CHUNK];
-  __shared__ float qs[128];
-  __shared__ float red[8];
-  __shared__ float part[4 * 128];
+// Decode attention, grouped-query aware: workgroup (sequence b, KV head kvh, chunk sp) takes keys [128 sp, 128 sp + 128) for ALL nh / nkv
+// query heads that share the KV head - the first split form ran one workgroup per QUERY head, so every key / value row crossed L2 -> L1
+// seven times at the 7B geometry, and it read K one row per lane (64 rows x 16 bytes per instruction: each 64-byte sector fetched four
+// times): 54 us per layer at 32 sequences x 528 keys, a fifth of the step. Here 16 lanes share a key (1 KiB contiguous per instruction),
+// the G dot products of a key come from one load, and a value row is multiplied into G outputs from one load. Writes the unnormalised
+// outputs, running maxima and sums per (head, chunk); vlm_attn_combine_kernel merges the chunks. Lk by value or, for graph replay, from
+// device memory (then the grid covers the whole cache and chunks past Lk write the neutral element).
+constexpr int VLM_DEC_CHUNK = 128;
+template <int G>
+__global__ __launch_bounds__(256) void vlm_attn_decode_gqa_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kc, const bf16* __restrict__ vc, float* __restrict__ po,
+                                                                  float* __restrict__ pm, float* __restrict__ pl, int nh, int nkv, int Lk, int max_seq, float scale,
+                                                                  const int* __restrict__ len_dev, int nsplit) {
+  __shared__ float sc[G][VLM_DEC_CHUNK];      // scores, then probabilities
+  __shared__ float part[4][G][128];
   if (len_dev) Lk = *len_dev + 1;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int bh = blockIdx.x, sp = blockIdx.y;
-  const int b = bh / nh, head = bh - b * nh, kvh = head / (nh / nkv);
+  const int bk = blockIdx.x, sp = blockIdx.y;
+  const int b = bk / nkv, kvh = bk - b * nkv, head0 = kvh * G;
   const int k0 = sp * VLM_DEC_CHUNK, k1 = min(k0 + VLM_DEC_CHUNK, Lk);
   if (k0 >= Lk) {      // a chunk past the cache length: neutral element of the merge
-    if (t == 0) { pm[(size_t)bh * nsplit + sp] = -INFINITY; pl[(size_t)bh * nsplit + sp] = 0.f; }
+    if (t < G) { pm[((size_t)b * nh + head0 + t) * nsplit + sp] = -INFINITY; pl[((size_t)b * nh + head0 + t) * nsplit + sp] = 0.f; }
     return;
   }
-  const bf16* K = kc + ((size_t)b * nkv + kvh) * max_seq * 128;
-  const bf16* V = vc + ((size_t)b * nkv + kvh) * max_seq * 128;
-  if (t < 128) qs[t] = (float)q[((size_t)b * nh + head) * 128 + t];
-  __syncthreads();
-  float s = -INFINITY;
-  const int key = k0 + t;
-  if (key < k1) {
-    const bf16* kr = K + (size_t)key * 128;
-    float acc = 0.f;
+  const bf16* const K = kc + ((size_t)b * nkv + kvh) * max_seq * 128;
+  const bf16* const V = vc + ((size_t)b * nkv + kvh) * max_seq * 128;
+  // ---- scores: 16 lanes per key (8 dims each), 4 keys per wave instruction, 32 keys per wave ---------------------------------------------
+  {
+    const int sub = lane & 15, kk = lane >> 4;
+    float qf[G][8];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      float v[8];
-      h_unpack8_bf16(*reinterpret_cast<const uint4*>(kr + 8 * c), v);
+    for (int g = 0; g < G; ++g) h_unpack8_bf16(*reinterpret_cast<const uint4*>(q + ((size_t)b * nh + head0 + g) * 128 + 8 * sub), qf[g]);
+    uint4 kr[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc += v[e] * qs[8 * c + e];
+    for (int it = 0; it < 8; ++it) {
+      const int key = k0 + wave * 32 + it * 4 + kk;
+      kr[it] = *reinterpret_cast<const uint4*>(K + (size_t)min(key, k1 - 1) * 128 + 8 * sub);
     }
-    s = acc * scale;
-  }
-  float mx = s;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const float e = key < k1 ? __expf(s - mx) : 0.f;
-  sc[t] = e;
-  float sum = e;
+    for (int it = 0; it < 8; ++it) {
+      const int kl = wave * 32 + it * 4 + kk;
+      float kf[8];
+      h_unpack8_bf16(kr[it], kf);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-  if (lane == 0) red[4 + wave] = sum;
-  __syncthreads();
-  // partial O: lane owns dims 2 lane, 2 lane + 1; wave w takes keys w, w + 4, ... of the chunk; probabilities as bf16 (the P operand)
-  float a0 = 0.f, a1 = 0.f;
-  for (int j = wave; j < k1 - k0; j += 4) {
-    const float pj = (float)(bf16)sc[j];
-    const unsigned u = *reinterpret_cast<const unsigned*>(V + (size_t)(k0 + j) * 128 + 2 * lane);
-    float v0, v1;
-    fe_unpack2((const bf16*)nullptr, u, v0, v1);
-    a0 += pj * v0; a1 += pj * v1;
+      for (int g = 0; g < G; ++g) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += kf[e] * qf[g][e];
+        a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+        if (sub == 0) sc[g][kl] = k0 + kl < k1 ? a * scale : -INFINITY;
+      }
+    }
   }
-  part[wave * 128 + 2 * lane] = a0; part[wave * 128 + 2 * lane + 1] = a1;
   __syncthreads();
-  if (t < 128) po[((size_t)bh * nsplit + sp) * 128 + t] = (part[t] + part[128 + t]) + (part[256 + t] + part[384 + t]);
-  if (t == 0) { pm[(size_t)bh * nsplit + sp] = mx; pl[(size_t)bh * nsplit + sp] = (red[4] + red[5]) + (red[6] + red[7]); }
+  // ---- softmax pieces per head: wave w takes heads w, w + 4; 2 keys per lane ---------------------------------------------------------------
+  for (int g = wave; g < G; g += 4) {
+    const float s0 = sc[g][lane], s1 = sc[g][64 + lane];
+    float mx = fmaxf(s0, s1);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    // probabilities as bf16 (the P operand of the reference's P V product)
+    const float e0 = (float)(bf16)__expf(s0 - mx), e1 = (float)(bf16)__expf(s1 - mx);
+    float sum = __expf(s0 - mx) + __expf(s1 - mx);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    sc[g][lane] = e0; sc[g][64 + lane] = e1;
+    if (lane == 0) { pm[((size_t)b * nh + head0 + g) * nsplit + sp] = mx; pl[((size_t)b * nh + head0 + g) * nsplit + sp] = sum; }
+  }
+  __syncthreads();
+  // ---- O partials: the same 16-lanes-per-row pattern on V (eight 1-KiB loads per wave in flight): lane (sub, kk) accumulates dims
+  // 8 sub .. 8 sub + 7 over keys 32 wave + 4 it + kk for every head; the four kk groups are then added with two shuffles -----------------------
+  {
+    const int sub = lane & 15, kk = lane >> 4;
+    uint4 vr[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int key = k0 + wave * 32 + it * 4 + kk;
+      vr[it] = *reinterpret_cast<const uint4*>(V + (size_t)min(key, k1 - 1) * 128 + 8 * sub);
+    }
+    float a[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[g][e] = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int kl = wave * 32 + it * 4 + kk;      // probabilities of keys past the chunk's end are zero
+      float vf[8];
+      h_unpack8_bf16(vr[it], vf);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float pj = sc[g][kl];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[g][e] += pj * vf[e];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = a[g][e];
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (kk == 0) part[wave][g][8 * sub + e] = v;
+      }
+  }
+  __syncthreads();
+  for (int i = t; i < G * 128; i += 256) {
+    const int g = i >> 7, dm = i & 127;
+    po[(((size_t)b * nh + head0 + g) * nsplit + sp) * 128 + dm] = (part[0][g][dm] + part[1][g][dm]) + (part[2][g][dm] + part[3][g][dm]);
+  }
 }
 __global__ void vlm_attn_combine_kernel(const float* __restrict__ po, const float* __restrict__ pm, const float* __restrict__ pl, bf16* __restrict__ o, int nsplit) {
   const int bh = blockIdx.x, t = threadIdx.x;      // 128 threads: one per output dimension
@@ -701,8 +866,19 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
     hipLaunchKernelGGL(vlm_rope_cache_kernel, dim3(grid_n((size_t)rows * (nh + 2 * nkv) * 64)), dim3(256), 0, c.stream, (const bf16*)qkv, pos, (const float*)m.inv_freq, qr,
                        m.kcache[li], m.vcache[li], rows, L, nh, nkv, g.mrope[0], g.mrope[1], start, m.max_seq, L == 1 ? len_dev : (const int*)nullptr);
     if (L == 1) {
-      hipLaunchKernelGGL(vlm_attn_decode_split_kernel, dim3(B * nh, nsplit), dim3(256), 0, c.stream, (const bf16*)qr, (const bf16*)m.kcache[li], (const bf16*)m.vcache[li],
-                         po, pm, pl, nh, nkv, Lk, m.max_seq, scale, len_dev, nsplit);
+      const int G = nh / nkv;
+#define VLM_DEC_LAUNCH(GG)                                                                                                                            \
+  hipLaunchKernelGGL(vlm_attn_decode_gqa_kernel<GG>, dim3(B * nkv, nsplit), dim3(256), 0, c.stream, (const bf16*)qr, (const bf16*)m.kcache[li],       \
+                     (const bf16*)m.vcache[li], po, pm, pl, nh, nkv, Lk, m.max_seq, scale, len_dev, nsplit)
+      switch (G) {
+        case 1: VLM_DEC_LAUNCH(1); break;
+        case 2: VLM_DEC_LAUNCH(2); break;
+        case 4: VLM_DEC_LAUNCH(4); break;
+        case 7: VLM_DEC_LAUNCH(7); break;
+        case 8: VLM_DEC_LAUNCH(8); break;
+        default: FE_CHECK(false, "vlm decode attention: %d query heads per KV head (1, 2, 4, 7, 8 are built)", G);
+      }
+#undef VLM_DEC_LAUNCH
       hipLaunchKernelGGL(vlm_attn_combine_kernel, dim3(B * nh), dim3(128), 0, c.stream, (const float*)po, (const float*)pm, (const float*)pl, ao, nsplit);
     } else {
       VlmAttnParams ap{qr, qd, m.kcache[li], m.vcache[li], ao, qd, B, nh, nkv, L, Lk, m.max_seq, start, scale};
@@ -711,6 +887,25 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
     FE_HIP(hipGetLastError());
     c.flops_accum += 4.0 * B * nh * (double)L * (start + (L + 1) * 0.5) * 128;
     c.flops_half += 4.0 * B * nh * (double)L * (start + (L + 1) * 0.5) * 128;
+    const bf16* const next_ln = li + 1 < m.layers.size() ? (const bf16*)m.layers[li + 1].ln1 : (const bf16*)nullptr;
+    // 5 .. 32 sequences: the split sums of the weight-streaming GEMM are taken by the pass that follows the projection (residual +
+    // norm, SwiGLU product) instead of a finishing launch of their own
+    const bool fused = d % 4 == 0 && m.inter % 4 == 0 && vlm_uses_gemm32(w.o, rows) && vlm_uses_gemm32(w.gate, rows) && vlm_uses_gemm32(w.up, rows) &&
+                       vlm_uses_gemm32(w.down, rows) && !w.o.shift && !w.gate.shift && !w.up.shift && !w.down.shift && w.gate.KpH == w.up.KpH;
+    if (fused) {
+      const size_t pm = c.arena.mark();
+      float *po_ = nullptr, *pg = nullptr, *pu = nullptr, *pd = nullptr;
+      int sp = vlm_gemm32_partials(c, w.o, (const bf16*)ao, qd, rows, &po_);
+      hipLaunchKernelGGL(vlm_finish_add_rmsnorm_kernel, dim3(rows), dim3(1024), 0, c.stream, (const float*)po_, sp, rows, d, (const float*)nullptr, x, (const bf16*)w.ln2, n, g.rms_eps);
+      const int sg = vlm_gemm32_partials(c, w.gate, (const bf16*)n, d, rows, &pg, &w.up, &pu);      // gate and up: one launch
+      const size_t mn4 = (size_t)rows * m.inter / 4;
+      hipLaunchKernelGGL(vlm_finish_silu_mul_kernel, dim3(grid_n(mn4)), dim3(256), 0, c.stream, (const float*)pg, (const float*)pu, sg, mn4, gg);
+      sp = vlm_gemm32_partials(c, w.down, (const bf16*)gg, m.inter, rows, &pd);
+      hipLaunchKernelGGL(vlm_finish_add_rmsnorm_kernel, dim3(rows), dim3(1024), 0, c.stream, (const float*)pd, sp, rows, d, (const float*)nullptr, x, next_ln, n, g.rms_eps);
+      FE_HIP(hipGetLastError());
+      c.arena.rewind(pm);
+      continue;
+    }
     vlm_linear(c, w.o, (const bf16*)ao, qd, rows, br, d);
     hipLaunchKernelGGL(vlm_add_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, x, (const bf16*)br, (const bf16*)w.ln2, n, rows, d, g.rms_eps);
     vlm_linear(c, w.gate, (const bf16*)n, d, rows, gg, m.inter);
@@ -718,8 +913,7 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
     hipLaunchKernelGGL(vlm_silu_mul_kernel, dim3(grid_n((size_t)rows * m.inter / 4)), dim3(256), 0, c.stream, (const bf16*)gg, (const bf16*)uu, gg, (size_t)rows * m.inter / 4);
     vlm_linear(c, w.down, (const bf16*)gg, m.inter, rows, br, d);
     // x += down(...) and, in the same launch, the next layer's input norm (none after the last layer)
-    hipLaunchKernelGGL(vlm_add_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, x, (const bf16*)br,
-                       li + 1 < m.layers.size() ? (const bf16*)m.layers[li + 1].ln1 : (const bf16*)nullptr, n, rows, d, g.rms_eps);
+    hipLaunchKernelGGL(vlm_add_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, x, (const bf16*)br, next_ln, n, rows, d, g.rms_eps);
     FE_HIP(hipGetLastError());
   }
   // final norm + lm_head on the last position of every sequence
@@ -728,8 +922,8 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
   hipLaunchKernelGGL(vlm_last_rows_kernel, dim3((B * d + 255) / 256), dim3(256), 0, c.stream, (const bf16*)x, last, B, L, d);
   hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)B * 64)), dim3(256), 0, c.stream, (const bf16*)last, d, (const bf16*)m.norm, lastn, d, B, d, g.rms_eps);
   float* lg = logits_dev ? logits_dev : c.arena.array<float>((size_t)B * m.vocab);
-  if (B <= 4) vlm_gemv(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab);
-  else if (B <= 32 && d % 64 == 0) vlm_gemm32(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab);
+  if (B <= 4 && !vlm_uses_gemm32(m.lm_head, B)) vlm_gemv(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab);
+  else if (B <= 32 && d % 128 == 0) vlm_gemm32(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab);
   else linear_forward_f32(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab, ACT_NONE);
   float* apv = c.arena.array<float>((size_t)B * VLM_AM_CHUNKS);
   int* api = c.arena.array<int>((size_t)B * VLM_AM_CHUNKS);
