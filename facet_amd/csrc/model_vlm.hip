@@ -623,9 +623,18 @@ __global__ void vlm_argmax_final_kernel(const float* __restrict__ pv, const int*
 // the G dot products of a key come from one load, and a value row is multiplied into G outputs from one load. Writes the unnormalised
 // outputs, running maxima and sums per (head, chunk); vlm_attn_combine_kernel merges the chunks. Lk by value or, for graph replay, from
 // device memory (then the grid covers the whole cache and chunks past Lk write the neutral element).
+// sum over the 16 lanes of a DPP row, result in every lane: four VALU adds with lane-permute modifiers (quad xor 1, quad xor 2, mirror of 8,
+// mirror of 16) - __shfl_xor goes through the LDS crossbar (ds_bpermute), ~20x the latency, and the score phase needs 28 sums per step
+__device__ __forceinline__ float vlm_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));       // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));      // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));      // row_mirror
+  return v;
+}
 constexpr int VLM_DEC_CHUNK = 128;
 template <int G>
-__global__ __launch_bounds__(256) void vlm_attn_decode_gqa_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kc, const bf16* __restrict__ vc, float* __restrict__ po,
+__global__ __launch_bounds__(256, 3) void vlm_attn_decode_gqa_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kc, const bf16* __restrict__ vc, float* __restrict__ po,
                                                                   float* __restrict__ pm, float* __restrict__ pl, int nh, int nkv, int Lk, int max_seq, float scale,
                                                                   const int* __restrict__ len_dev, int nsplit) {
   __shared__ float sc[G][VLM_DEC_CHUNK];      // scores, then probabilities
@@ -663,7 +672,7 @@ __global__ __launch_bounds__(256) void vlm_attn_decode_gqa_kernel(const bf16* __
         float a = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) a += kf[e] * qf[g][e];
-        a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+        a = vlm_row16_sum(a);
         if (sub == 0) sc[g][kl] = k0 + kl < k1 ? a * scale : -INFINITY;
       }
     }
