@@ -965,7 +965,9 @@ void vlm_decode_steps(Ctx& c, VlmModel& m, int* tok_dev, int* pos_dev, int B, in
   const int len0 = m.cur_len;
   one_step();                                      // outside the graph: first-use attributes (dynamic LDS sizes) are set here
   static const bool no_graph = getenv("FE_VLM_NO_GRAPH") != nullptr;      // A/B hook
-  if (n_steps > 1 && !no_graph) {
+  // replayed from a graph the ~60 launches of a step carry a dependency edge each: worth it while the step is launch-bound (1-2 sequences:
+  // 0.68 vs 0.70 ms per 4-layer step), slower than back-to-back stream launches above that (32 sequences: 1.21 vs 1.10 ms; profiles/r03_vlm_perf.txt)
+  if (n_steps > 1 && !no_graph && B <= 2) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     FE_HIP(hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal));
