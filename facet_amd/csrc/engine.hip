@@ -682,6 +682,16 @@ void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, floa
     c.flops_accum += 2.0 * M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : w.Cout);
     return;
   }
+  if (M <= 128 && (size_t)w.K * w.Cout >= (1u << 20) && !res && act != ACT_PRELU && c.force_variant == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w.w) & 15) == 0 &&
+      !getenv("FE_NO_SKINNY128")) {
+    // 33 .. 128 rows against a weight matrix of a megaword and more (SAMP-Net's pattern layers at a micro-batch of 64: K = 2592 .. 7524,
+    // N = 1024): one tile row of the convolution kernel walks K serially on N / 128 CUs (1.6 TFLOP/s, 0.6 ms for the largest); streaming
+    // the weights once per 32 rows is ~30x faster even though it reads them ceil(M / 32) times
+    for (int m0 = 0; m0 < M; m0 += 32)
+      launch_gemm_skinny(x + (size_t)m0 * ldx, ldx, w.w, w.Kp, w.scale, w.shift, y + (size_t)m0 * ldy, ldy, std::min(32, M - m0), w.Cout, w.K, act, c.stream);
+    c.flops_accum += 2.0 * M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : w.Cout);
+    return;
+  }
   Tensor xt = mat_view(x, M, w.CinPad, ldx), yt = mat_view(y, M, w.Cout, ldy);
   ConvOpts o; o.act = act;
   Tensor rt;
