@@ -82,20 +82,21 @@ def test_device_resident_generate_equals_the_stepwise_path(vlm_engine):
 
 
 def test_decode_kernels_agree_across_batch_sizes(vlm_engine):
-    """The three decode projection paths - streaming GEMV (<= 4 sequences), weight-streaming matrix-core GEMM with a K split (5 .. 32),
-    the shared tiled GEMM (> 32) - on the same sequences: 4 prompts alone, the same 4 inside batches of 8, 32 and 40. Planted read-out,
-    so the token ids must be identical; logits within one bf16 unit of their scale (different summation orders of the same products)."""
+    """The three decode projection paths - streaming GEMV (<= 3 sequences), weight-streaming matrix-core GEMM with a K split whose sums
+    are taken by the fused residual / norm / SwiGLU passes (4 .. 32), the shared tiled GEMM (> 32) - on the same sequences: 3 prompts
+    alone, the same 3 inside batches of 4, 8, 32 and 40. Planted read-out, so the token ids must be identical; logits within one bf16 unit
+    of their scale (different summation orders of the same products)."""
     e = vlm_engine
     e.load_weights(FE_MODEL_VLM, _planted(7))
     rng = np.random.default_rng(12)
-    p4 = rng.integers(0, 2048, (4, 21)).astype(np.int32)
-    t4, l4 = e.vlm_generate(p4, 6, want_logits=True)
-    for B in (8, 32, 40):
-        pb = np.concatenate([p4] + [rng.integers(0, 2048, (B - 4, 21)).astype(np.int32)], 0)
+    p3 = rng.integers(0, 2048, (3, 21)).astype(np.int32)
+    t3, l3 = e.vlm_generate(p3, 6, want_logits=True)
+    for B in (4, 8, 32, 40):
+        pb = np.concatenate([p3] + [rng.integers(0, 2048, (B - 3, 21)).astype(np.int32)], 0)
         tb, lb = e.vlm_generate(pb, 6, want_logits=True)
-        assert np.array_equal(tb[:4], t4), B
-        assert np.abs(lb[:4] - l4).max() <= 0.125, (B, float(np.abs(lb[:4] - l4).max()))
-        assert np.array_equal(e.vlm_generate(pb, 6)[:4], t4), B          # device-resident loop, same kernels
+        assert np.array_equal(tb[:3], t3), B
+        assert np.abs(lb[:3] - l3).max() <= 0.125, (B, float(np.abs(lb[:3] - l3).max()))
+        assert np.array_equal(e.vlm_generate(pb, 6)[:3], t3), B          # device-resident loop, same kernels
 
 
 def test_teacher_forced_logits_of_the_random_checkpoint(vlm_engine):
@@ -116,16 +117,19 @@ def test_teacher_forced_logits_of_the_random_checkpoint(vlm_engine):
 
 def test_decode_step_equals_prefill_of_the_longer_prompt(vlm_engine):
     """KV-cache consistency: prefill(L) + one decode step sees the same keys as prefill(L + 1) - different attention kernels (matrix-core
-    tiles vs the streaming single-query pass), same logits up to bf16 rounding of the attention output."""
+    tiles vs the grouped-query single-query pass over key chunks + merge), same logits up to bf16 rounding of the attention output."""
     e = vlm_engine
     e.load_weights(FE_MODEL_VLM, synthetic_state_dict("qwen2_5_vl_text_tiny", 5))
     rng = np.random.default_rng(3)
-    for L in (1, 31, 32, 33, 129, 200):
-        p = rng.integers(0, 2048, (3, L + 1)).astype(np.int32)
-        _, full = e.vlm_prefill(p, want_logits=True)
-        e.vlm_prefill(p[:, :L], max_seq=L + 8)
-        _, step = e.vlm_decode_step(p[:, L], np.full((3, 3), L, np.int32), want_logits=True)
-        assert np.abs(full - step).max() <= 0.0625, (L, float(np.abs(full - step).max()))
+    # cache lengths on both sides of the decode attention's 128-key chunks (1 .. 5 chunks), with 3 sequences (GEMV projections) and 6
+    # (matrix-core projections + fused finishing passes)
+    for B, Ls in ((3, (1, 31, 32, 33, 127, 128, 129, 200, 300, 517)), (6, (5, 130, 300))):
+        for L in Ls:
+            p = rng.integers(0, 2048, (B, L + 1)).astype(np.int32)
+            _, full = e.vlm_prefill(p, want_logits=True)
+            e.vlm_prefill(p[:, :L], max_seq=L + 8)
+            _, step = e.vlm_decode_step(p[:, L], np.full((3, B), L, np.int32), want_logits=True)
+            assert np.abs(full - step).max() <= 0.0625, (B, L, float(np.abs(full - step).max()))
 
 
 def _hf_model(cfg, sd, mrope, theta, eps):
