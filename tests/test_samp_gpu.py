@@ -68,3 +68,19 @@ def test_samp_against_live_oracle_other_seed_and_ragged_batch(engine):
     assert np.abs(gsal - sal.numpy()).max() < 1e-4
     assert np.abs(pw - rpw.numpy()).max() / np.abs(rpw.numpy()).max() < 1e-3
     assert np.abs(at - rat.numpy()).max() < 1e-3 and np.abs(sd - rsd.numpy()).max() < 1e-3
+
+
+def test_micro_batches_of_8_and_40_take_different_head_kernels_and_agree(engine, samp_loaded, gold):
+    """SAMP-Net's pattern layers (K = 2592 .. 7524 -> 1024) run on the skinny GEMM for <= 32 rows, on the same kernel per block of 32
+    rows for 33 .. 128 (engine.hip linear_forward), and the small heads on the tiled kernel above 32 rows: 40 images scored as one
+    micro-batch of 40 and as five of 8 agree to fp32 summation-order noise, with the dominant pattern identical."""
+    x = torch.randn(40, 3, 224, 224, generator=torch.Generator().manual_seed(77)).numpy()
+    engine.set_microbatch(8)
+    a = engine.samp_forward(x)
+    engine.set_microbatch(64)
+    b = engine.samp_forward(x)
+    engine.set_microbatch(8)
+    for u, v in zip(a, b):
+        assert u.shape == v.shape
+        assert np.abs(u - v).max() <= 2e-5 * max(1.0, float(np.abs(u).max()))
+    assert np.array_equal(a[0].argmax(1), b[0].argmax(1))
