@@ -61,7 +61,7 @@ POLICY_NOTE = {
     "reference_gpu": "the reference's own GPU precisions: CLIP in fp16 (`self.model.half()`, processing/scorer.py:513-516; aesthetic MLP fp32 "
                      "on the fp32 features as there), everything else fp32",
     "parity": "precision policy PARITY (facet_amd/precision.py): the fastest per-model assignment whose final scores stay within SURVEY 8(d)'s "
-              f"1e-3 of the fp32 oracle - TOPIQ fp16, U2-Net-P fp16, SAMP-Net fp32, CLIP split-operand fp16 (every GEMM operand an fp16 pair hi + lo, "
+              f"1e-3 of the fp32 oracle - TOPIQ fp16 (images below 256 x 256 pixels on its fp32 weights: none in this workload), U2-Net-P fp16, SAMP-Net fp32, CLIP split-operand fp16 (every GEMM operand an fp16 pair hi + lo, "
               f"3x the matrix work of plain fp16; {HALF_NOTE})",
     "fast16": "precision policy FAST16: TOPIQ / U2-Net-P fp16, CLIP and SAMP-Net fp16 with fp32 residual streams (scores within 5e-3, "
               f"embedding cosine >= 1 - 1e-6: outside the 1e-3 gate; {HALF_NOTE})",
