@@ -868,7 +868,13 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
   float* po = nsplit ? c.arena.array<float>((size_t)B * nh * nsplit * 128) : nullptr;
   float* pm = nsplit ? c.arena.array<float>((size_t)B * nh * nsplit) : nullptr;
   float* pl = nsplit ? c.arena.array<float>((size_t)B * nh * nsplit) : nullptr;
-  hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, (const bf16*)x, d, (const bf16*)m.layers[0].ln1, n, d, rows, d, g.rms_eps);
+  // (few rows: one 1024-thread workgroup per row - the wave-per-row kernel walks a 3584-wide row in 14 dependent steps, 11 us for 32 rows;
+  // with no split sums to take, the finishing pass is x = bf16(x + 0), n = RMSNorm(x) w)
+  const bool few_rows = rows <= 64 && d % 4 == 0;
+  if (few_rows)
+    hipLaunchKernelGGL(vlm_finish_add_rmsnorm_kernel, dim3(rows), dim3(1024), 0, c.stream, (const float*)nullptr, 0, rows, d, (const float*)nullptr, x, (const bf16*)m.layers[0].ln1, n, g.rms_eps);
+  else
+    hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)rows * 64)), dim3(256), 0, c.stream, (const bf16*)x, d, (const bf16*)m.layers[0].ln1, n, d, rows, d, g.rms_eps);
   for (size_t li = 0; li < m.layers.size(); ++li) {
     const VlmLayerW& w = m.layers[li];
     vlm_linear(c, w.qkv, (const bf16*)n, d, rows, qkv, qkvd);
@@ -929,7 +935,10 @@ void vlm_forward(Ctx& c, VlmModel& m, bf16* x, const int* pos, int B, int L, int
   bf16* last = c.arena.array<bf16>((size_t)B * d);
   bf16* lastn = c.arena.array<bf16>((size_t)B * d);
   hipLaunchKernelGGL(vlm_last_rows_kernel, dim3((B * d + 255) / 256), dim3(256), 0, c.stream, (const bf16*)x, last, B, L, d);
-  hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)B * 64)), dim3(256), 0, c.stream, (const bf16*)last, d, (const bf16*)m.norm, lastn, d, B, d, g.rms_eps);
+  if (B <= 64 && d % 4 == 0)
+    hipLaunchKernelGGL(vlm_finish_add_rmsnorm_kernel, dim3(B), dim3(1024), 0, c.stream, (const float*)nullptr, 0, B, d, (const float*)nullptr, last, (const bf16*)m.norm, lastn, g.rms_eps);
+  else
+    hipLaunchKernelGGL(vlm_rmsnorm_kernel, dim3(grid_n((size_t)B * 64)), dim3(256), 0, c.stream, (const bf16*)last, d, (const bf16*)m.norm, lastn, d, B, d, g.rms_eps);
   float* lg = logits_dev ? logits_dev : c.arena.array<float>((size_t)B * m.vocab);
   if (B <= 4 && !vlm_uses_gemm32(m.lm_head, B)) vlm_gemv(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab);
   else if (B <= 32 && d % 128 == 0) vlm_gemm32(c, m.lm_head, (const bf16*)lastn, d, B, lg, m.vocab);
