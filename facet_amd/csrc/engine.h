@@ -166,6 +166,9 @@ struct ResBlock {
   void* frag2 = nullptr;
   void* frag3 = nullptr;
 };
+// kernels_n16.hip: fp32 3x3 convolution to 16 output channels (U2-Net-P's REBNCONV mid layers)
+float* build_n16_weights(DeviceWeights& dw, const float* W, int cin);
+void launch_conv3x3_n16_f32(const Tensor& x, const Tensor& y, const float* wt, const float* scale, const float* shift, int act, hipStream_t s);
 // fragment blobs of kernels_c64.hip (W2 [64][64][3][3]; W3 [256][64] or null: the plain 3x3)
 void build_c64_fragments(DeviceWeights& dw, const float* W2, const float* W3, void** frag2, void** frag3);
 template <class E>

@@ -282,6 +282,7 @@ struct ConvW {
   int wino_m = 0;          // 2 or 4: which Winograd form `wino` holds (F(2x2,3x3): 16 planes, F(4x4,3x3): 36 planes)
   float* wino = nullptr;   // 3x3 convs with Cin >= 256 also carry Winograd F(2x2,3x3) weights U[16][Cout][Cin]
   float* wstem = nullptr;  // 7x7 or 3x3, Cin <= 3, Cout 32|64 stems also carry the [taps][Cout][4] layout of kernels_stem.hip
+  float* wn16 = nullptr;   // fp32 3x3 layers with 16 output channels and 16 / 32 / 64 input channels also carry the layout of kernels_n16.hip
   int KpT = 0;
   // 2-byte path (models committed under FE_PRECISION_BF16 / FE_PRECISION_F16): [Cout][KpH] elements of type `hprec` in the K
   // order of kernels_conv_bf16.hip

@@ -15,7 +15,13 @@ namespace fe {
 static RSUW build_rsu(DeviceWeights& dw, const WeightStore& ws, const std::string& p, int depth, bool dilated) {
   RSUW r;
   r.depth = depth; r.dilated = dilated;
-  auto cbr = [&](const std::string& n) { return build_conv(dw, ws, p + "." + n + ".conv_s1", p + "." + n + ".bn_s1", true); };
+  auto cbr = [&](const std::string& n) {
+    ConvW w = build_conv(dw, ws, p + "." + n + ".conv_s1", p + "." + n + ".bn_s1", true);
+    const HostTensor& W = ws.get(p + "." + n + ".conv_s1.weight");
+    if (dw.prec == PREC_F32 && W.shape.size() == 4 && W.shape[0] == 16 && W.shape[2] == 3 && W.shape[3] == 3 && (W.shape[1] == 16 || W.shape[1] == 32 || W.shape[1] == 64))
+      w.wn16 = build_n16_weights(dw, W.data.data(), (int)W.shape[1]);
+    return w;
+  };
   r.in = cbr("rebnconvin");
   for (int k = 1; k <= depth; ++k) r.enc.push_back(cbr("rebnconv" + std::to_string(k)));
   for (int k = depth - 1; k >= 1; --k) r.dec.push_back(cbr("rebnconv" + std::to_string(k) + "d"));  // dec[0] = (L-1)d ... dec[L-2] = 1d
@@ -36,6 +42,26 @@ static inline int ceil_half(int v) { return (v + 1) / 2; }  // MaxPool2d(2, stri
 
 template <class T>
 static void cbr(Ctx& c, const ConvW& w, const TensorT<T>& x, const TensorT<T>& y, int dil, const TensorT<T>* res_after = nullptr) {
+  if constexpr (sizeof(T) == 4) {
+    // 16-output-channel layers on large maps: the 16-column matrix instruction, halo-tiled (kernels_n16.hip)
+    if (w.wn16 && dil == 1 && !res_after && x.c == w.Cin && y.c == 16 && x.pixels() >= 65536 && x.ld % 4 == 0 && y.ld % 4 == 0 && !getenv("FE_NO_N16")) {
+      const double flops = 2.0 * (double)y.pixels() * 9.0 * w.Cin * 16;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (c.profile) { FE_HIP(hipEventCreate(&e0)); FE_HIP(hipEventCreate(&e1)); FE_HIP(hipEventRecord(e0, c.stream)); }
+      launch_conv3x3_n16_f32(x, y, w.wn16, w.scale, w.shift, ACT_RELU, c.stream);
+      if (c.profile) {
+        FE_HIP(hipEventRecord(e1, c.stream)); FE_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        FE_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        char nm[128];
+        snprintf(nm, sizeof nm, "halo-tiled conv3x3 -> 16 (16x16x4 f32) M=%d K=%d", (int)y.pixels(), 9 * w.Cin);
+        c.timings.push_back({nm, flops, 4.0 * (double)y.pixels() * (w.Cin + 16), ms});
+      }
+      c.flops_accum += flops;
+      return;
+    }
+  }
   ConvOptsT<T> o; o.ph = o.pw = dil; o.dh = o.dw = dil; o.act = ACT_RELU;
   if (res_after) { o.res = res_after; o.res_after_act = 1; }
   conv_forward(c, w, x, y, o);
