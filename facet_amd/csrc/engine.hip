@@ -333,12 +333,13 @@ void conv_forward(Ctx& c, const ConvW& w, const Tensor& x, const Tensor& y, cons
       return;
     }
   }
-  // Split-K for few-row, long-K products (ArcFace's 25088 -> 512 embedding layer on a handful of faces): a single tile row would walk K
+  // Split-K for few-row, long-K products (ArcFace's 25088 -> 512 embedding layer on a handful of faces; SAMP-Net's eight pattern layers,
+  // K = 2592 .. 7524 -> 1024, at micro-batches above 32 rows: SAMP stage 3290 -> 3330 images/s): a single tile row would walk K
   // serially on Cout/64 CUs. K is cut into equal slices that run as ONE batched launch into [splits][M][Cout] partials, which
   // splitk_reduce sums in a fixed order and finishes with the epilogue.
   static const bool no_splitk = getenv("FE_NO_SPLITK") != nullptr;
   if (!no_splitk && w.KH == 1 && w.KW == 1 && o.sh == 1 && o.sw == 1 && o.ph == 0 && o.pw == 0 && !o.gate && p.variant == 0 && p.M <= 256 &&
-      w.CinPad >= 4096 && w.K == w.CinPad && (size_t)((p.M + 127) / 128) * ((w.Cout + 63) / 64) < 64 &&
+      w.CinPad >= (getenv("FE_SPLITK_MIN") ? atoi(getenv("FE_SPLITK_MIN")) : 2048) && w.K == w.CinPad &&      // (A/B hook; 4096 until round 3) (size_t)((p.M + 127) / 128) * ((w.Cout + 63) / 64) < 64 &&
       (o.act == ACT_NONE || o.act == ACT_RELU || o.act == ACT_PRELU)) {
     int splits = 0;
     for (int s = 64; s >= 2; --s)
@@ -679,16 +680,6 @@ void linear_forward(Ctx& c, const ConvW& w, const float* x, int ldx, int M, floa
   if (M <= 32 && !res && act != ACT_PRELU && c.force_variant == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w.w) & 15) == 0) {
     // per-image vectors: stream the weight matrix once instead of idling 255 CUs behind one 128-row tile
     launch_gemm_skinny(x, ldx, w.w, w.Kp, w.scale, w.shift, y, ldy, M, w.Cout, w.K, act, c.stream);
-    c.flops_accum += 2.0 * M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : w.Cout);
-    return;
-  }
-  if (M <= 128 && (size_t)w.K * w.Cout >= (1u << 20) && !res && act != ACT_PRELU && c.force_variant == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w.w) & 15) == 0 &&
-      !getenv("FE_NO_SKINNY128")) {
-    // 33 .. 128 rows against a weight matrix of a megaword and more (SAMP-Net's pattern layers at a micro-batch of 64: K = 2592 .. 7524,
-    // N = 1024): one tile row of the convolution kernel walks K serially on N / 128 CUs (1.6 TFLOP/s, 0.6 ms for the largest); streaming
-    // the weights once per 32 rows is ~30x faster even though it reads them ceil(M / 32) times
-    for (int m0 = 0; m0 < M; m0 += 32)
-      launch_gemm_skinny(x + (size_t)m0 * ldx, ldx, w.w, w.Kp, w.scale, w.shift, y + (size_t)m0 * ldy, ldy, std::min(32, M - m0), w.Cout, w.K, act, c.stream);
     c.flops_accum += 2.0 * M * (double)w.Cin * (w.CoutAlg ? w.CoutAlg : w.Cout);
     return;
   }

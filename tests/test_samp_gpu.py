@@ -70,10 +70,11 @@ def test_samp_against_live_oracle_other_seed_and_ragged_batch(engine):
     assert np.abs(at - rat.numpy()).max() < 1e-3 and np.abs(sd - rsd.numpy()).max() < 1e-3
 
 
-def test_micro_batches_of_8_and_40_take_different_head_kernels_and_agree(engine, samp_loaded, gold):
-    """SAMP-Net's pattern layers (K = 2592 .. 7524 -> 1024) run on the skinny GEMM for <= 32 rows, on the same kernel per block of 32
-    rows for 33 .. 128 (engine.hip linear_forward), and the small heads on the tiled kernel above 32 rows: 40 images scored as one
-    micro-batch of 40 and as five of 8 agree to fp32 summation-order noise, with the dominant pattern identical."""
+def test_micro_batches_of_8_and_40_take_different_kernels_and_agree(engine, samp_loaded, gold):
+    """40 images scored as one micro-batch of 40 and as five of 8: SAMP-Net's pattern layers (K = 2592 .. 7524 -> 1024) run on the skinny
+    GEMM for <= 32 rows and on the tiled kernel with a K split above; U2-Net-P's 16-channel 3x3 layers run on the halo-tiled 16-column
+    kernel (kernels_n16.hip, partial tiles at 56 x 56) once a map has >= 65536 pixels and on the generic kernel below. The results agree
+    to fp32 summation-order noise, with the dominant pattern identical."""
     x = torch.randn(40, 3, 224, 224, generator=torch.Generator().manual_seed(77)).numpy()
     engine.set_microbatch(8)
     a = engine.samp_forward(x)
