@@ -12,6 +12,7 @@
 // (tests/golden/make_vlm_golden.py) - pinned.
 // Not in this slice: the vision tower (window attention, patch merger) and fp8 attention; image tokens enter as rows of `embeds`.
 #include "engine.h"
+#include <type_traits>
 #include <cmath>
 
 namespace fe {
@@ -439,7 +440,10 @@ __global__ void vlm_gemm32_finish_kernel(const float* __restrict__ part, int spl
   stf(y + (size_t)m * ldy + n, s + v);
 }
 // launches the partial products of y = x W^T into `part` ([splits][M][N] fp32, taken from the arena: the CALLER rewinds); returns the split count
-static int vlm_gemm32_partials(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float** part, const ConvW* w2 = nullptr, float** part2 = nullptr) {
+// `direct` (optional): where the result may be written straight when the layer needs no K split - a single split's partial sums ARE the
+// product (the 152064-row lm_head: 1188 workgroup columns already fill the chip), so its finishing pass is skipped by the caller
+static int vlm_gemm32_partials(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, float** part, const ConvW* w2 = nullptr, float** part2 = nullptr,
+                               float* direct = nullptr) {
   const int K = w.CinPadH, N = w.Cout;
   FE_CHECK(w.wh && w.hprec == PREC_BF16 && !w.scale && K % 128 == 0 && w.KpH % 8 == 0 && ldx % 8 == 0 && M >= 1 && M <= 32, "vlm_gemm32: unsupported layer");
   FE_CHECK(!w2 || (w2->wh && w2->hprec == PREC_BF16 && !w2->scale && w2->CinPadH == K && w2->Cout == N && w2->KpH == w.KpH && part2), "vlm_gemm32: the paired matrix differs in shape");
@@ -449,7 +453,7 @@ static int vlm_gemm32_partials(Ctx& c, const ConvW& w, const bf16* x, int ldx, i
   int splits = std::max(1, std::min(nst / 4, (768 + allcols - 1) / allcols));
   const int per = (nst + splits - 1) / splits;
   splits = (nst + per - 1) / per;
-  *part = c.arena.array<float>((size_t)splits * M * N);
+  *part = splits == 1 && direct ? direct : c.arena.array<float>((size_t)splits * M * N);
   if (w2) *part2 = c.arena.array<float>((size_t)splits * M * N);
   hipLaunchKernelGGL(vlm_gemm32_kernel, dim3(allcols, splits), dim3(256), 0, c.stream, x, ldx, (const bf16*)w.wh, w.KpH, *part, M, N, K, per,
                      w2 ? (const bf16*)w2->wh : (const bf16*)nullptr, w2 ? *part2 : (float*)nullptr, cols);
@@ -462,10 +466,14 @@ template <class TO>
 static void vlm_gemm32(Ctx& c, const ConvW& w, const bf16* x, int ldx, int M, TO* y, int ldy) {
   const size_t mark = c.arena.mark();
   float* part = nullptr;
-  const int splits = vlm_gemm32_partials(c, w, x, ldx, M, &part), N = w.Cout;
-  hipLaunchKernelGGL((vlm_gemm32_finish_kernel<TO>), dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, c.stream, (const float*)part, splits, M, N,
-                     (const float*)w.shift, y, ldy);
-  FE_HIP(hipGetLastError());
+  float* direct = nullptr;
+  if constexpr (std::is_same<TO, float>::value) { if (!w.shift && ldy == w.Cout) direct = y; }
+  const int splits = vlm_gemm32_partials(c, w, x, ldx, M, &part, nullptr, nullptr, direct), N = w.Cout;
+  if (!(direct && part == direct)) {
+    hipLaunchKernelGGL((vlm_gemm32_finish_kernel<TO>), dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, c.stream, (const float*)part, splits, M, N,
+                       (const float*)w.shift, y, ldy);
+    FE_HIP(hipGetLastError());
+  }
   c.arena.rewind(mark);
 }
 static bool vlm_uses_gemm32(const ConvW& w, int M) {
