@@ -121,3 +121,33 @@ def test_topiq_scores_with_and_without_the_fused_gate():
     rel = lambda a, b: (np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max()
     assert rel(out["fused"], out["unfused"]) < 1e-3, out
     assert rel(out["fused"], out["f32"]) < 1e-3, out
+
+
+def test_fused_kernels_at_baseline_size_against_the_unfused_forms_and_fp32():
+    """BASELINE's image size: two 1024 x 1024 images through fp16 TOPIQ with every fused 64-channel kernel on (level-0 gate + pool on the
+    512 x 512 map, the three chained bottleneck tails and the halo-tiled gate 3x3 on 256 x 256) and with all of them off
+    (FE_NO_FUSED_GATE, FE_NO_FUSED_C64), and through the fp32 engine: within 1e-3 of each other and of fp32."""
+    from facet_amd import Engine
+    from facet_amd._lib import FE_MODEL_TOPIQ
+    from facet_amd.weights import synthetic_images, synthetic_state_dict
+    sd = synthetic_state_dict("topiq", 13)
+    imgs = synthetic_images(17, 2, 1024, 1024)
+    out = {}
+    for name, prec, off in (("f32", "f32", False), ("fused", "f16", False), ("unfused", "f16", True)):
+        for k in ("FE_NO_FUSED_GATE", "FE_NO_FUSED_C64"):
+            os.environ.pop(k, None)
+            if off:
+                os.environ[k] = "1"
+        try:
+            e = Engine(0, arena_bytes=16 << 30, precision=prec)
+            e.load_weights(FE_MODEL_TOPIQ, sd)
+            e.set_microbatch(2)
+            out[name] = np.asarray(e.topiq_score(imgs), np.float64)
+            e.close()
+        finally:
+            os.environ.pop("FE_NO_FUSED_GATE", None)
+            os.environ.pop("FE_NO_FUSED_C64", None)
+    print("[fused kernels @1024]", out)
+    rel = lambda a, b: (np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max()
+    assert rel(out["fused"], out["unfused"]) < 1e-3, out
+    assert rel(out["fused"], out["f32"]) < 1e-3, out
